@@ -1,0 +1,135 @@
+/*
+ * monorun_pnp.h — C ABI of libmonorun_pnp.so (MI355X / gfx950 HIP implementation of MonoRUn's
+ * uncertainty-aware 4-DoF PnP hot path).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Reference interfaces replaced (paths relative to the MonoRUn tree, /root/reference):
+ *   - monorun/ops/least_squares/src/ext.h:1-13 .......... `pnp_uncert` (per-object, host fp64 buffers;
+ *     bound by cffi in monorun/ops/least_squares/setup.py:12-24, called at pnp_uncert_cpu.py:102-106)
+ *   - monorun/ops/least_squares/pnp_uncert_cpu.py:128-209  `u2d_pnp_cpu` (batch driver: istd mask,
+ *     EPnP/RANSAC initialiser, per-object LM)  +  monorun/ops/least_squares/pnp_uncert.py:60-85
+ *     (approx Hessian + inverse)  ->  `mr_pnp_uncert_batched` (one fused kernel, device pointers)
+ *   - the elementwise decode chain in front of the PnP (fcn_noc_decoder.py:225-267, noc_coder.py:50-73,
+ *     multiclass_norm_dim_coder.py:28-36, distance_invar_proj_error_coder.py:39-60,
+ *     uncert_prop_pnp_optimizer.py:73-88, roi_align of coord_2d at monorun_roi_head.py:521-523)
+ *     -> `mr_noc_decode_batched`
+ *
+ * Conventions: every function returns 0 on success or a negative MR_ERR_* code; nothing is allocated
+ * that the caller must free; device entry points are asynchronous on the given HIP stream and touch
+ * only caller-owned memory.  Numerical failure of a solve is reported per object in `valid`,
+ * never as an error code (pnp_uncert_cpu.py:119-125).
+ */
+#ifndef MONORUN_PNP_H_
+#define MONORUN_PNP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_PNP_VERSION 100            /* 0.1.0 */
+
+/* input element types of the correspondence tensors */
+#define MR_F32 0
+#define MR_F16 1
+#define MR_F64 2
+
+/* error codes */
+#define MR_OK                 0
+#define MR_ERR_BAD_ARGUMENT  (-1)
+#define MR_ERR_UNSUPPORTED   (-2)     /* P too large for LDS, unknown dtype, ... */
+#define MR_ERR_HIP           (-3)     /* a HIP runtime call failed; see mr_pnp_last_hip_error() */
+#define MR_ERR_NO_DEVICE     (-4)
+
+/* flags for mr_pnp_uncert_batched */
+#define MR_MEAN_AUTO          0x0     /* pick numpy's order from the istd strides (see below) */
+#define MR_MEAN_SEQUENTIAL    0x1     /* numpy order for a C-contiguous (B,P,2) float32 array */
+#define MR_MEAN_PAIRWISE      0x2     /* numpy order when the point axis is the contiguous one */
+#define MR_MEAN_MASK          0x3
+#define MR_NO_ISTD_MASK       0x4     /* skip the istd inlier test: every point is a candidate */
+#define MR_COV_NONE           0x8     /* do not compute the pose covariance (cov left untouched) */
+#define MR_COV_CERES          0x10    /* covariance with the solver's (Ceres/autodiff) Jacobian instead of the
+                                         torch Jacobian of jacobian.py (what `pnp_uncert`'s result_cov is) */
+#define MR_WAVES_SHIFT        8       /* bits 8..11: wavefronts cooperating on one object (0 = auto, 1,2,4,8) */
+#define MR_WAVES_MASK         (0xF << MR_WAVES_SHIFT)
+
+/* diag[] layout (per object, 4 floats): */
+#define MR_DIAG_LM_ITERATIONS 0       /* LM loop passes executed                                  */
+#define MR_DIAG_FINAL_COST    1       /* 1/2 sum r^2 at the returned pose                          */
+#define MR_DIAG_WHY           2       /* 1 gradient tol, 2 parameter tol, 3 function tol, 4 max iterations,
+                                         5 min radius, 6 invalid steps (failure), 7 evaluation failure,
+                                         8 initialiser failed (no LM run)                            */
+#define MR_DIAG_K0_COUNT      3       /* consensus size of the winning hypothesis (or candidate count) */
+
+int mr_pnp_version(void);
+const char *mr_pnp_error_string(int code);
+int mr_pnp_last_hip_error(void);
+int mr_pnp_device_count(void);
+
+/*
+ * Batched uncertainty-aware PnP: for each of B objects with P correspondences
+ *   candidates  = istd >= istd_thres * mean_P(istd) on both axes  (all points if <= 4 pass)   [R4]
+ *   init, mask  = deterministic consensus initialiser K0 (or `init_pose` if given)              [R5]
+ *   pose        = trust-region LM (Ceres 1.14 defaults) on the weighted reprojection residuals  [R1,R3]
+ *   cov         = inverse(J^T J) at the float32 pose, torch Jacobian masking semantics          [R2,R6,R7]
+ *
+ * x2d/istd/x3d: device pointers to (B,P,2)/(B,P,2)/(B,P,3) tensors of `in_dtype` addressed as
+ *   base[b*strides[0] + p*strides[1] + c*strides[2]] (strides in ELEMENTS).  Both layouts the pipeline
+ *   produces are fast paths: channel-planar views of NCHW maps (strides {C*P,1,P}) and contiguous
+ *   (B,P,C) (strides {C*P,C,1}).
+ * cam_mats: device float (cam_batch,3,3), cam_batch in {1,B}.   u_range/v_range: device float
+ *   (range_batch,2), range_batch in {1,B}.   ransac_thr: device float (B) or NULL (no consensus step).
+ * init_pose: device double (B,4) [yaw,tx,ty,tz] or NULL.  When given, K0 is skipped and the
+ *   candidate set is used as the inlier set.
+ * outputs (device): valid (B) u8; pose (B,4) f32 [yaw,tx,ty,tz]; cov (B,16) f32 row-major;
+ *   tr_radius (B) f32; inlier_mask (B,P) u8; diag (B,4) f32 or NULL.
+ * stream: hipStream_t (NULL = default stream).
+ */
+int mr_pnp_uncert_batched(
+    const void *x2d, const int64_t *x2d_strides,
+    const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides,
+    int in_dtype,
+    const float *cam_mats, int cam_batch,
+    const float *u_range, const float *v_range, int range_batch,
+    const float *ransac_thr,
+    const double *init_pose,
+    int B, int P,
+    float z_min, float istd_thres, int inlier_opt_only, int flags,
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
+    void *stream);
+
+/*
+ * The reference's own per-object C entry point, same signature and semantics (ext.h:1-13,
+ * pnp_uncert_cpu.cpp:245-292): HOST fp64 buffers in, host results out; runs the same LM kernel on the
+ * GPU for one object (blocking).  result_cov may be NULL; on failure result_cov is left untouched.
+ */
+void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose,
+                int *result_val, double *result_pose, double *result_cov, double *result_tr,
+                int pn, double *clips);
+
+/*
+ * Fused NOC-head post-processing ("K2"): from the raw head output to the PnP-boundary tensors.
+ *   all_pred  (B, 2*C*5, h, w) f32  — conv_final output (C = num_classes, or 1 if class_agnostic)
+ *   labels (B) int64, flip (B) u8, dim (B,3) f32 normalised dims, dim_var (B,3) f32 or NULL,
+ *   rois (B,4) f32 xyxy in the test-scale image
+ * writes channel-planar maps
+ *   coords_2d (B,2,h,w), coords_2d_istd (B,2,h,w), coords_3d (B,3,h,w)   [all f32]
+ *   dims (B,3), dims_var (B,3) (optional), ransac_thr (B) (optional)
+ */
+int mr_noc_decode_batched(
+    const float *all_pred, const int64_t *labels, const uint8_t *flip,
+    const float *dim, const float *dim_var, const float *rois,
+    int B, int num_classes, int class_agnostic, int h, int w,
+    const float *dim_means /* (C,3) */, const float *dim_stds /* (C,3) */,
+    const float *noc_means /* 3 */, const float *noc_stds /* 3 */,
+    float proj_scaling_denominator, float ref_focal_y, float epistemic_std_gain,
+    float std_scale, float ransac_thres_ratio,
+    float *coords_2d, float *coords_2d_istd, float *coords_3d,
+    float *dims, float *dims_var, float *ransac_thr,
+    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONORUN_PNP_H_ */

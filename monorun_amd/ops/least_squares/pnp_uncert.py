@@ -1,0 +1,163 @@
+"""Torch-facing uncertainty-aware PnP op — drop-in for
+/root/reference/monorun/ops/least_squares/pnp_uncert.py (``pnp_uncert`` :7-87, ``PnPUncert`` :90-142).
+
+Same names, argument meaning, return tuple, dtypes and devices.  What differs is the execution:
+the reference copies six tensors to the host, loops over objects in Python (cv2 EPnP/RANSAC + cffi
+Ceres LM), copies back and builds J^T J with ~40 small torch kernels; here ONE fused HIP kernel
+(``mr_pnp_uncert_batched`` in include/monorun_pnp.h) does mask -> initialiser -> LM -> covariance on the
+device, on the caller's stream, with no host synchronisation.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from .builder import PNP
+
+_DTYPES = {torch.float32: _lib.MR_F32, torch.float16: _lib.MR_F16, torch.float64: _lib.MR_F64}
+
+
+def _strides(t):
+    return (ctypes.c_int64 * 3)(*t.stride())
+
+
+def pnp_uncert_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5,
+                      epnp_istd_thres=1.0, epnp_ransac_thres=None, inlier_opt_only=False,
+                      init_pose=None, flags=0, with_diag=False):
+    """Launch the fused kernel on CUDA(HIP) tensors; returns raw device outputs
+    (valid u8 (B,), pose f32 (B,4), cov f32 (B,4,4), tr f32 (B,), mask u8 (B,P), diag f32 (B,4)|None)."""
+    lib = _lib.load()
+    dev = coords_2d.device
+    if dev.type != 'cuda':
+        raise RuntimeError('monorun_amd PnP runs on an MI355X only: inputs must be on a HIP device '
+                           '(there is no CPU fallback)')
+    B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+    dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
+
+    def prep(t):
+        t = t.detach()
+        return t if (t.dtype == dt and t.device == dev) else t.to(device=dev, dtype=dt)
+    x2d, istd, x3d = prep(coords_2d), prep(coords_2d_istd), prep(coords_3d)
+    assert x2d.shape == (B, P, 2) and istd.shape == (B, P, 2) and x3d.shape == (B, P, 3)
+    f32 = dict(device=dev, dtype=torch.float32)
+    cam = cam_mats.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    ur = u_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    vr = v_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    assert ur.shape[0] == vr.shape[0]
+    thr = epnp_ransac_thres.detach().to(**f32).reshape(-1).contiguous() if epnp_ransac_thres is not None else None
+    ini = init_pose.detach().to(device=dev, dtype=torch.float64).reshape(-1, 4).contiguous() if init_pose is not None else None
+    valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    pose = torch.empty(B, 4, **f32)
+    cov = torch.empty(B, 4, 4, **f32)
+    tr = torch.empty(B, **f32)
+    mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    diag = torch.empty(B, 4, **f32) if with_diag else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.mr_pnp_uncert_batched(
+                x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt],
+                cam.data_ptr(), cam.shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                thr.data_ptr() if thr is not None else None, ini.data_ptr() if ini is not None else None, B, P,
+                float(z_min), float(epnp_istd_thres), int(bool(inlier_opt_only)), int(flags),
+                valid.data_ptr(), pose.data_ptr(), cov.data_ptr(), tr.data_ptr(), mask.data_ptr(),
+                diag.data_ptr() if diag is not None else None, stream))
+    return valid, pose, cov, tr, mask, diag
+
+
+def pnp_uncert(coords_2d, coords_2d_istd, coords_3d,
+               cam_mats, u_range, v_range, z_min=0.5,
+               epnp_istd_thres=1.0, epnp_ransac_thres=None,
+               inlier_opt_only=False, forward_exact_hessian=False,
+               use_6dof=False):
+    """
+    Args:
+        coords_2d (torch.Tensor): shape (Nbatch, Npoint, 2)
+        coords_2d_istd (torch.Tensor): shape (Nbatch, Npoint, 2)
+        coords_3d (torch.Tensor): shape (Nbatch, Npoint, 3)
+        cam_mats (torch.Tensor): shape (Nbatch, 3, 3) or (1, 3, 3)
+        u_range (torch.Tensor): shape (Nbatch, 2) or (1, 2)
+        v_range (torch.Tensor): shape (Nbatch, 2) or (1, 2)
+        z_min (float):
+        epnp_istd_thres (float):
+        epnp_ransac_thres (None | torch.Tensor): shape (Nbatch, )
+        inlier_opt_only (bool):
+        forward_exact_hessian (bool): only False is supported (every shipped config, e.g.
+            configs/kitti_car.py:123; the reference's exact_hessian no longer runs on torch>=2)
+        use_6dof (bool): accepted and ignored, exactly as in the reference (pnp_uncert.py:11)
+
+    Returns:
+        ret_val (Tensor): shape (Nbatch, ), validity bool mask
+        r_vec (Tensor): shape (Nbatch, 1)
+        t_vec (Tensor): shape (Nbatch, 3)
+        pose_cov (Tensor): shape (Nbatch, 4, 4), covariance matrices of [yaw, t_vec]
+        inlier_mask (Tensor): shape (Nbatch, Npoint), inlier bool mask
+    """
+    if forward_exact_hessian:
+        raise NotImplementedError('forward_exact_hessian=True is not supported (unused by every reference config)')
+    with torch.no_grad():
+        src_dev = coords_2d.device
+        if src_dev.type != 'cuda':
+            if not torch.cuda.is_available():
+                raise RuntimeError('monorun_amd.ops.pnp_uncert needs an MI355X (HIP) device; no CPU fallback exists')
+            dev = torch.device('cuda', torch.cuda.current_device())
+            mv = lambda t: t.to(dev) if t is not None else None
+            coords_2d, coords_2d_istd, coords_3d = mv(coords_2d), mv(coords_2d_istd), mv(coords_3d)
+        valid, pose, cov, _, mask, _ = pnp_uncert_device(
+            coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=z_min,
+            epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres, inlier_opt_only=inlier_opt_only)
+        odt = coords_2d.dtype
+        ret_val = valid.to(device=src_dev, dtype=torch.bool)
+        r_vec = pose[:, :1].to(device=src_dev, dtype=odt)
+        t_vec = pose[:, 1:].to(device=src_dev, dtype=odt)
+        pose_cov = cov.to(device=src_dev, dtype=odt)
+        inlier_mask = mask.to(device=src_dev, dtype=torch.bool)
+    return ret_val, r_vec, t_vec, pose_cov, inlier_mask
+
+
+@PNP.register_module()
+class PnPUncert(torch.nn.Module):
+
+    def __init__(self, z_min=0.5,
+                 epnp_istd_thres=0.6,
+                 inlier_opt_only=True,
+                 coord_istd_normalize=False,
+                 forward_exact_hessian=False,
+                 use_6dof=False,
+                 eps=1e-6):
+        """Uncertainty-2D PnP (same constructor as the reference, pnp_uncert.py:93-99).
+
+        Args:
+            z_min (float):
+            epnp_istd_thres (float): points with istd greater than (thres
+                * istd_mean) will be kept as inliers
+            inlier_opt_only (bool): whether to use inliers or all points for
+                non-linear optimization
+        """
+        super(PnPUncert, self).__init__()
+        self.z_min = z_min
+        self.epnp_istd_thres = epnp_istd_thres
+        self.inlier_opt_only = inlier_opt_only
+        self.coord_istd_normalize = coord_istd_normalize
+        self.forward_exact_hessian = forward_exact_hessian
+        self.use_6dof = use_6dof
+        self.eps = eps
+
+    def forward(self,
+                coords_2d, coords_2d_istd,
+                coords_3d,
+                cam_mats,
+                u_range, v_range, epnp_ransac_thres=None):
+        if self.coord_istd_normalize:
+            mean = torch.mean(coords_2d_istd, dim=(1, 2), keepdim=True)
+            coords_2d_istd = coords_2d_istd / mean.clamp(min=self.eps)
+        return pnp_uncert(
+            coords_2d, coords_2d_istd,
+            coords_3d,
+            cam_mats,
+            u_range, v_range, z_min=self.z_min,
+            epnp_istd_thres=self.epnp_istd_thres,
+            epnp_ransac_thres=epnp_ransac_thres,
+            inlier_opt_only=self.inlier_opt_only,
+            forward_exact_hessian=self.forward_exact_hessian,
+            use_6dof=self.use_6dof)

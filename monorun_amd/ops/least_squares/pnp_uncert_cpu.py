@@ -1,0 +1,82 @@
+"""numpy-level batch driver — drop-in for ``u2d_pnp_cpu`` of
+/root/reference/monorun/ops/least_squares/pnp_uncert_cpu.py:128-209 (same name, arguments and
+6-tuple).  Despite the inherited name nothing is solved on the CPU: the arrays are staged to the
+MI355X (keeping their strides, which select numpy's summation order for the istd mean), the fused
+HIP kernel runs, and the results come back as numpy arrays.
+"""
+import numpy as np
+import torch
+
+from ... import _lib
+from .pnp_uncert import pnp_uncert_device
+
+
+def _to_dev(a, dev):
+    """numpy -> device tensor with the SAME element strides (no re-layout)."""
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float16, np.float64):
+        a = a.astype(np.float32)
+    if not a.flags.writeable:
+        a = a.copy()
+    t = torch.from_numpy(a)
+    d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev)
+    d.copy_(t)
+    return d
+
+
+def u2d_pnp_cpu(coords_2d, coords_2d_istd,
+                coords_3d,
+                cam_mats,
+                u_range, v_range, z_min=0.5,
+                epnp_istd_thres=1.0,
+                epnp_ransac_thres=None,
+                inlier_opt_only=False,
+                with_pose_cov=True):
+    """
+    Args:
+        coords_2d (ndarray): shape (Nbatch, Npoint, 2)
+        coords_2d_istd (ndarray): shape (Nbatch, Npoint, 2)
+        coords_3d (ndarray): shape (Nbatch, Npoint, 3)
+        cam_mats (ndarray): shape (Nbatch, 3, 3) or (1, 3, 3)
+        u_range (ndarray): shape (Nbatch, 2) or (1, 2)
+        v_range (ndarray): shape (Nbatch, 2) or (1, 2)
+        z_min (float):
+        epnp_istd_thres (float):
+        epnp_ransac_thres (None | ndarray): shape (Nbatch, )
+        inlier_opt_only (bool):
+
+    Returns:
+        ret_val (ndarray): shape (Nbatch, ), validity bool mask
+        yaw (ndarray): shape (Nbatch, 1)
+        t_vec (ndarray): shape (Nbatch, 3)
+        pose_cov (ndarray): shape (Nbatch, 4, 4), covariance matrices
+            of [yaw, t_vec]; here (J^T J)^-1 with the solver's Jacobian, as Ceres'
+            Covariance returns it (pnp_uncert_cpu.cpp:279-291); None if not with_pose_cov
+        tr_radius (ndarray): shape (Nbatch, 1), trust region radius
+        inlier_mask (ndarray): shape (Nbatch, Npoint), inlier bool mask
+    """
+    bn = coords_2d.shape[0]
+    pn = coords_2d.shape[1]
+    if bn == 0:
+        return (np.zeros((0, ), dtype=bool), np.zeros((0, 1), dtype=np.float32), np.zeros((0, 3), dtype=np.float32),
+                np.zeros((0, 4, 4), dtype=np.float32), np.zeros((0, 1), dtype=np.float32), np.zeros((0, pn), dtype=bool))
+    assert coords_2d_istd.shape[1] == coords_3d.shape[1] == pn >= 4
+    if not torch.cuda.is_available():
+        raise RuntimeError('monorun_amd.ops.u2d_pnp_cpu needs an MI355X (HIP) device; no CPU fallback exists')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    flags = _lib.MR_COV_CERES if with_pose_cov else _lib.MR_COV_NONE
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    valid, pose, cov, tr, mask, _ = pnp_uncert_device(
+        _to_dev(coords_2d, dev), _to_dev(coords_2d_istd, dev), _to_dev(coords_3d, dev),
+        t(cam_mats), t(u_range), t(v_range), z_min=z_min, epnp_istd_thres=epnp_istd_thres,
+        epnp_ransac_thres=t(epnp_ransac_thres) if epnp_ransac_thres is not None else None,
+        inlier_opt_only=inlier_opt_only, flags=flags)
+    ret_val = valid.cpu().numpy().astype(bool)
+    pose = pose.cpu().numpy()
+    if with_pose_cov:
+        pose_cov = cov.cpu().numpy()
+        pose_cov[~ret_val] = np.eye(4, dtype=np.float32)      # result_cov keeps its identity init on failure (:93,:119-125)
+    else:
+        pose_cov = None
+    return (ret_val, pose[:, :1].copy(), pose[:, 1:].copy(), pose_cov,
+            tr.cpu().numpy()[:, None], mask.cpu().numpy().astype(bool))

@@ -1,0 +1,271 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/pnp_oracle.c header).
+
+Python face of the CPU restatement: ctypes bindings to ``libpnp_oracle.so`` plus numpy
+restatements of the host-side / elementwise stages of the reference hot path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module;
+``monorun_amd`` never does.
+
+Reference rows restated here in numpy, paths relative to /root/reference:
+  R4  istd inlier mask ........ monorun/ops/least_squares/pnp_uncert_cpu.py:164-168
+  R8  pose-head input prep .... monorun/models/roi_heads/bbox_3d_heads/optimizers/uncert_prop_pnp_optimizer.py:73-97
+  R9  flip/class channel pick . monorun/models/roi_heads/bbox_3d_heads/dense_decoders/fcn_noc_decoder.py:225-267
+  R10 dim / NOC decode ........ monorun/core/bbox_3d/dim_coder/multiclass_norm_dim_coder.py:28-36,
+                                monorun/core/bbox_3d/coord_coder/noc_coder.py:50-73
+  R11 log-std decode .......... monorun/core/bbox_3d/proj_error_coder/distance_invar_proj_error_coder.py:39-60
+  R12 roi_align(coord_2d) ..... monorun/models/roi_heads/monorun_roi_head.py:521-523 (analytic interior form;
+                                mmcv absent -> border behaviour unpinned)
+  R13 cov_correction .......... distance_invar_proj_error_coder.py:62-63
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_fp = ctypes.POINTER(ctypes.c_float)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'libpnp_oracle.so')
+    src = os.path.join(_HERE, 'pnp_oracle.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libpnp_oracle.so'],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_max_threads.restype = ctypes.c_int
+        _LIB.orc_k0_init.restype = ctypes.c_int
+        _LIB.orc_pose_cov.restype = ctypes.c_int
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+# ----------------------------------------------------------------------------- C restatement ---
+def pnp_uncert(pts2d, pts3d, wgt2d, K, init_pose, clips, with_cov=False):
+    """The reference's C entry point (src/ext.h:1-13): returns dict(val, pose, cov, tr, diag)."""
+    pts2d, pts3d, wgt2d, K, init_pose, clips = map(_d, (pts2d, pts3d, wgt2d, K, init_pose, clips))
+    pn = pts2d.shape[0]
+    val = np.zeros(1, np.int32)
+    pose = np.zeros(4)
+    cov = np.eye(4) if with_cov else None
+    tr = np.zeros(1)
+    diag = np.zeros(6)
+    lib().orc_pnp_uncert_diag(_p(pts2d, c_dp), _p(pts3d, c_dp), _p(wgt2d, c_dp), _p(K, c_dp),
+                              _p(init_pose, c_dp), _p(val, c_ip), _p(pose, c_dp), _p(cov, c_dp),
+                              _p(tr, c_dp), ctypes.c_int(pn), _p(clips, c_dp), _p(diag, c_dp))
+    return dict(val=int(val[0]), pose=pose, cov=cov, tr=float(tr[0]),
+                iters=int(diag[0]), why=int(diag[1]), termination=int(diag[2]),
+                initial_cost=diag[3], final_cost=diag[4], n_success=int(diag[5]))
+
+
+def residual_jacobian(K, clips, pose, pts2d, pts3d, wgt2d):
+    """R1: Ceres-semantics residuals (pn,2) and Jacobian (pn,2,4)."""
+    pts2d, pts3d, wgt2d, K, pose, clips = map(_d, (pts2d, pts3d, wgt2d, K, pose, clips))
+    pn = pts2d.shape[0]
+    res = np.zeros((pn, 2))
+    jac = np.zeros((pn, 2, 4))
+    lib().orc_residual_jacobian(_p(K, c_dp), _p(clips, c_dp), _p(pose, c_dp), _p(pts2d, c_dp),
+                                _p(pts3d, c_dp), _p(wgt2d, c_dp), ctypes.c_int(pn), _p(res, c_dp), _p(jac, c_dp))
+    return res, jac
+
+
+def torch_jacobian(K, z_min, u_range, v_range, yaw, t, pts2d, pts3d, istd, inlier=None):
+    """R2/R7 for one object: jac (pn,2,4) [yaw,tx,ty,tz], weighted err (pn,2), H = J^T J (4,4)."""
+    pts2d, pts3d, istd, K, u_range, v_range, t = map(_d, (pts2d, pts3d, istd, K, u_range, v_range, t))
+    pn = pts2d.shape[0]
+    jac = np.zeros((pn, 2, 4))
+    err = np.zeros((pn, 2))
+    H = np.zeros((4, 4))
+    inl = np.ascontiguousarray(inlier, np.uint8) if inlier is not None else None
+    lib().orc_torch_jacobian(_p(K, c_dp), ctypes.c_double(z_min), _p(u_range, c_dp), _p(v_range, c_dp),
+                             ctypes.c_double(float(yaw)), _p(t, c_dp), _p(pts2d, c_dp), _p(pts3d, c_dp),
+                             _p(istd, c_dp), _p(inl, c_u8p), ctypes.c_int(pn), _p(jac, c_dp), _p(err, c_dp), _p(H, c_dp))
+    return jac, err, H
+
+
+def pose_cov(H):
+    H = _d(H)
+    cov = np.zeros((4, 4))
+    ok = lib().orc_pose_cov(_p(H, c_dp), _p(cov, c_dp))
+    return bool(ok), cov
+
+
+def k0_init(x2d, x3d, mask0, K, ransac_thr=None, n_hyp=32):
+    """K0 for one object.  Returns dict(ok, init_pose, mask, best_hyp, best_count)."""
+    x2d, x3d, K = _f(x2d), _f(x3d), _f(K)
+    mask = np.ascontiguousarray(mask0, np.uint8).copy()
+    init = np.zeros(4)
+    bh = np.zeros(1, np.int32)
+    bc = np.zeros(1, np.int32)
+    ok = lib().orc_k0_init(_p(x2d, c_fp), _p(x3d, c_fp), _p(mask, c_u8p), ctypes.c_int(x2d.shape[0]), _p(K, c_fp),
+                           ctypes.c_int(ransac_thr is not None), ctypes.c_float(0.0 if ransac_thr is None else float(ransac_thr)),
+                           ctypes.c_int(n_hyp), _p(init, c_dp), _p(bh, c_ip), _p(bc, c_ip))
+    return dict(ok=bool(ok), init_pose=init, mask=mask.astype(bool), best_hyp=int(bh[0]), best_count=int(bc[0]))
+
+
+def istd_inlier_mask(coords_2d_istd, epnp_istd_thres):
+    """R4 (pnp_uncert_cpu.py:164-168) — literally the reference's numpy expression, so the float32
+    summation order numpy picks for the array's strides is the reference's own."""
+    mean = np.mean(coords_2d_istd, axis=1, keepdims=True)
+    return np.min(coords_2d_istd >= epnp_istd_thres * mean, axis=2)
+
+
+def u2d_pnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5,
+            epnp_istd_thres=1.0, epnp_ransac_thres=None, inlier_opt_only=False,
+            init_pose=None, n_hyp=32, num_threads=1, return_diag=False):
+    """R4+R5+R6 for a batch (the numpy-level driver).  Returns the reference's 6-tuple
+    (ret_val, yaw, t_vec, pose_cov, tr_radius, inlier_mask) [+ diag]; pose_cov is the
+    torch-semantics inverse(J^T J) that pnp_uncert.py:71-85 computes."""
+    B, P = coords_2d.shape[:2]
+    if B == 0:
+        out = (np.zeros((0,), bool), np.zeros((0, 1), np.float32), np.zeros((0, 3), np.float32),
+               np.zeros((0, 4, 4), np.float32), np.zeros((0, 1), np.float32), np.zeros((0, P), bool))
+        return out + (np.zeros((0, 4), np.float32),) if return_diag else out
+    assert coords_2d_istd.shape[1] == coords_3d.shape[1] == P >= 4
+    mask = np.ascontiguousarray(istd_inlier_mask(coords_2d_istd, epnp_istd_thres), np.uint8)
+    x2d, istd, x3d = _f(coords_2d), _f(coords_2d_istd), _f(coords_3d)
+    K = _f(cam_mats).reshape(-1, 9)
+    ur, vr = _f(u_range).reshape(-1, 2), _f(v_range).reshape(-1, 2)
+    assert ur.shape[0] == vr.shape[0]
+    thr = _f(epnp_ransac_thres) if epnp_ransac_thres is not None else None
+    ini = _d(init_pose) if init_pose is not None else None
+    valid = np.zeros(B, np.uint8)
+    pose = np.zeros((B, 4), np.float32)
+    cov = np.zeros((B, 16), np.float32)
+    tr = np.zeros(B, np.float32)
+    diag = np.zeros((B, 4), np.float32)
+    lib().orc_u2d_pnp_batch(_p(x2d, c_fp), _p(istd, c_fp), _p(x3d, c_fp), _p(K, c_fp), ctypes.c_int(K.shape[0]),
+                            _p(ur, c_fp), _p(vr, c_fp), ctypes.c_int(ur.shape[0]), _p(thr, c_fp), _p(ini, c_dp),
+                            ctypes.c_int(B), ctypes.c_int(P), ctypes.c_double(z_min), ctypes.c_int(bool(inlier_opt_only)),
+                            ctypes.c_int(n_hyp), ctypes.c_int(num_threads), _p(mask, c_u8p), _p(valid, c_u8p),
+                            _p(pose, c_fp), _p(cov, c_fp), _p(tr, c_fp), _p(diag, c_fp))
+    out = (valid.astype(bool), pose[:, :1].copy(), pose[:, 1:].copy(), cov.reshape(B, 4, 4),
+           tr[:, None].copy(), mask.astype(bool))
+    return out + (diag,) if return_diag else out
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+# ------------------------------------------------------------------ numpy restatements (fp32) ---
+NOC_MEANS = np.array((-0.1, -0.5, 0.0), np.float32)      # noc_coder.py:9
+NOC_STDS = np.array((0.35, 0.23, 0.34), np.float32)      # noc_coder.py:10
+DIM_MEANS = np.array([(3.89, 1.53, 1.62), (0.82, 1.78, 0.63), (1.77, 1.72, 0.57)], np.float32)  # multiclass_norm_dim_coder.py:8-11
+DIM_STDS = np.array([(0.44, 0.14, 0.11), (0.25, 0.13, 0.12), (0.15, 0.10, 0.14)], np.float32)   # :12-15
+
+
+def slice_pred(all_pred, labels, flip, num_classes=3, class_agnostic=False):
+    """R9: flip-branch select (fcn_noc_decoder.py:225-235) + class channel gather (:242-267).
+    all_pred (B, 2*C*5, h, w) -> noc (B,3,h,w), logstd (B,2,h,w).  Also returns the int channel
+    table (B,5): channel of noc comp k = f*5C + 3c + k ; log-std comp k = f*5C + 3C + 2c + k."""
+    B, ch, h, w = all_pred.shape
+    C = 1 if class_agnostic else num_classes
+    assert ch == 2 * C * 5
+    flip = np.broadcast_to(np.asarray(flip, bool), (B,)).astype(np.int64)
+    labels = np.zeros(B, np.int64) if class_agnostic else np.asarray(labels, np.int64)
+    chan = np.empty((B, 5), np.int64)
+    for k in range(3):
+        chan[:, k] = flip * 5 * C + 3 * labels + k
+    for k in range(2):
+        chan[:, 3 + k] = flip * 5 * C + 3 * C + 2 * labels + k
+    ar = np.arange(B)
+    noc = np.stack([all_pred[ar, chan[:, k]] for k in range(3)], axis=1)
+    logstd = np.stack([all_pred[ar, chan[:, 3 + k]] for k in range(2)], axis=1)
+    return noc, logstd, chan
+
+
+def dim_decode(dim, dim_var, labels):
+    """R10a (multiclass_norm_dim_coder.py:28-36)."""
+    mu, sd = DIM_MEANS[labels], DIM_STDS[labels]
+    dims = dim * sd + mu
+    return dims, (dim_var * np.square(sd) if dim_var is not None else None)
+
+
+def noc_decode(noc, dims, dims_var):
+    """R10b (noc_coder.py:50-73) for the test-time case noc_var=None."""
+    part = noc * NOC_STDS[:, None, None] + NOC_MEANS[:, None, None]
+    c3d = part * dims[..., None, None]
+    var = dims_var[..., None, None] * np.square(part) if dims_var is not None else None
+    return c3d, var
+
+
+def decode_logstd(proj_logstd, c3d_var, ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0):
+    """R11 (distance_invar_proj_error_coder.py:39-60) with distance=None."""
+    sd = np.float32(ref_length * ref_focal_y * target_std)
+    if c3d_var is None:
+        return proj_logstd + np.log(sd / sd)
+    v2 = np.empty(proj_logstd.shape, np.float32)
+    v2[:, 0] = np.float32(0.5) * (c3d_var[:, 0] + c3d_var[:, 2])
+    v2[:, 1] = c3d_var[:, 1]
+    v2 = (v2 * np.float32((ref_focal_y * epistemic_std_gain) ** 2)
+          + np.exp(np.float32(2) * proj_logstd) * np.float32(sd ** 2)) / np.square(sd)
+    return (np.float32(0.5) * np.log(v2)).astype(np.float32)
+
+
+def roi_grid(rois_xyxy, h=28, w=28):
+    """R12, interior analytic form of roi_align(coord_2d, rois, (h,w), 1.0, 0, 'avg', aligned=True):
+    u(px) = x1 - 0.5 + (px + 0.5) * (x2 - x1) / w  (mmcv absent -> border unpinned)."""
+    r = np.asarray(rois_xyxy, np.float32)
+    x1, y1, x2, y2 = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+    px = (np.arange(w, dtype=np.float32) + np.float32(0.5))
+    py = (np.arange(h, dtype=np.float32) + np.float32(0.5))
+    u = (x1 - np.float32(0.5))[:, None] + px[None, :] * ((x2 - x1) / np.float32(w))[:, None]
+    v = (y1 - np.float32(0.5))[:, None] + py[None, :] * ((y2 - y1) / np.float32(h))[:, None]
+    out = np.empty((r.shape[0], 2, h, w), np.float32)
+    out[:, 0] = u[:, None, :]
+    out[:, 1] = v[:, :, None]
+    return out
+
+
+def pose_head_prep(coords_2d, coords_2d_logstd, coords_3d, img_shapes, allowed_border=200,
+                   epnp_ransac_thres_ratio=0.2, std_scale=10):
+    """R8 (uncert_prop_pnp_optimizer.py:73-88): NCHW maps -> the PnP boundary tensors, keeping the
+    reference's *strided views* (permute(0,2,3,1).view -> strides (C*hw, 1, hw))."""
+    bn, _, h, w = coords_2d.shape
+    istd = (np.exp(-coords_2d_logstd) / np.float32(std_scale)).astype(np.float32)
+    img_shapes = np.asarray(img_shapes, np.float32).reshape(-1, 2)
+    u_range = np.full((img_shapes.shape[0], 2), -allowed_border, np.float32)
+    v_range = np.full((img_shapes.shape[0], 2), -allowed_border, np.float32)
+    u_range[:, 1] = img_shapes[:, 1] + allowed_border
+    v_range[:, 1] = img_shapes[:, 0] + allowed_border
+    def pv(a):
+        return a.reshape(bn, a.shape[1], h * w).transpose(0, 2, 1)
+    roi_h = coords_2d[:, 1, -1, 0] - coords_2d[:, 1, 0, 0]
+    thr = (np.float32(epnp_ransac_thres_ratio) * roi_h).astype(np.float32) if epnp_ransac_thres_ratio is not None else None
+    return pv(coords_2d), pv(istd), pv(coords_3d), u_range, v_range, thr
+
+
+def cov_calib(pose_cov, cov_calib_logscale):
+    """uncert_prop_pnp_optimizer.py:96-97."""
+    s = np.exp(np.asarray(cov_calib_logscale, np.float32))
+    return (s * s[:, None]) * pose_cov
+
+
+def cov_correction(cov, t_vec, ref_length=1.6, ref_focal_y=722, target_std=0.15):
+    """R13 (distance_invar_proj_error_coder.py:62-63 with 'range' distance, uncert_projection_head.py:104-109)."""
+    sd = np.float32(ref_length * ref_focal_y * target_std)
+    dist = np.linalg.norm(t_vec.astype(np.float32), axis=1)
+    return cov * np.square(sd / dist).reshape(-1, 1, 1)

@@ -1,0 +1,584 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product.
+ *
+ * Plain-C, scalar, fp64 CPU restatement of MonoRUn's uncertainty-aware 4-DoF PnP hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * monorun_amd/ never imports, links or calls anything in oracle/.
+ *
+ * What is restated, and from where (paths relative to /root/reference):
+ *   R1  residual + autodiff Jacobian ........ monorun/ops/least_squares/src/pnp_uncert_cpu.cpp:24-51
+ *        (Jet arithmetic + AngleAxisRotatePoint: Ceres Solver 1.14.0 jet.h / rotation.h —
+ *         third-party, NOT in the reference tree, pinned by INSTALL.md:29; restated from the
+ *         published algorithm)
+ *   R3  LM driver, options, outputs .......... pnp_uncert_cpu.cpp:245-292  (+ Ceres 1.14
+ *        TrustRegionMinimizer / LevenbergMarquardtStrategy defaults, restated)
+ *   R2/R7 torch-semantics Jacobian and J^T J . monorun/ops/least_squares/jacobian.py:4-98,141-167,
+ *        hessian.py:67-87
+ *   R6  pose covariance inverse(J^T J) ....... monorun/ops/least_squares/pnp_uncert.py:60-85
+ *   R5  per-object driver .................... monorun/ops/least_squares/pnp_uncert_cpu.py:11-125
+ *   K0  initialiser: the reference calls cv2.solvePnPRansac/solvePnP(EPNP) (pnp_uncert_cpu.py:35-58);
+ *        OpenCV is absent everywhere, so K0 here restates THIS repo's documented deterministic
+ *        replacement, not OpenCV.
+ *
+ * PARITY STATUS: residual/Jacobian/J^T J/covariance are pinned against golden vectors produced by
+ * importing the reference's jacobian.py / hessian.py (tests/golden/make_golden.py).  The LM
+ * *stopping iterate* follows Ceres 1.14 from its documentation/recollection of its source and is
+ * "parity unpinned" against a real Ceres binary (none can be built here); the LM *solution* is
+ * pinned against scipy.optimize.least_squares and noise-free known-answer cubes.  K0 is unpinned
+ * against OpenCV by construction.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off, the reference's own -O2; no -march).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <float.h>
+#include <stdlib.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Minimal forward-mode dual number with 4 partials: the arithmetic Ceres' Jet<double,4> does.
+ * (Ceres 1.14 include/ceres/jet.h — restated; formulas for *, /, sqrt, sin, cos as published.)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double a; double v[4]; } jet4;
+
+static jet4 j_const(double c) { jet4 r; r.a = c; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.0; return r; }
+static jet4 j_var(double c, int k) { jet4 r = j_const(c); r.v[k] = 1.0; return r; }
+static jet4 j_add(jet4 f, jet4 g) { jet4 r; r.a = f.a + g.a; for (int i = 0; i < 4; ++i) r.v[i] = f.v[i] + g.v[i]; return r; }
+static jet4 j_sub(jet4 f, jet4 g) { jet4 r; r.a = f.a - g.a; for (int i = 0; i < 4; ++i) r.v[i] = f.v[i] - g.v[i]; return r; }
+static jet4 j_mul(jet4 f, jet4 g) { jet4 r; r.a = f.a * g.a; for (int i = 0; i < 4; ++i) r.v[i] = f.a * g.v[i] + f.v[i] * g.a; return r; }
+static jet4 j_div(jet4 f, jet4 g) {
+    jet4 r; const double gi = 1.0 / g.a; const double q = f.a * gi;
+    r.a = q; for (int i = 0; i < 4; ++i) r.v[i] = (f.v[i] - q * g.v[i]) * gi; return r;
+}
+static jet4 j_sqrt(jet4 f) { jet4 r; const double t = sqrt(f.a); const double h = 1.0 / (2.0 * t); r.a = t; for (int i = 0; i < 4; ++i) r.v[i] = f.v[i] * h; return r; }
+static jet4 j_cos(jet4 f) { jet4 r; const double s = -sin(f.a); r.a = cos(f.a); for (int i = 0; i < 4; ++i) r.v[i] = s * f.v[i]; return r; }
+static jet4 j_sin(jet4 f) { jet4 r; const double c = cos(f.a); r.a = sin(f.a); for (int i = 0; i < 4; ++i) r.v[i] = c * f.v[i]; return r; }
+
+/* Ceres rotation.h AngleAxisRotatePoint, templated on T = jet4 (restated). */
+static void j_angle_axis_rotate_point(const jet4 aa[3], const jet4 pt[3], jet4 out[3]) {
+    jet4 theta2 = j_add(j_add(j_mul(aa[0], aa[0]), j_mul(aa[1], aa[1])), j_mul(aa[2], aa[2]));
+    if (theta2.a > DBL_EPSILON) {
+        jet4 theta = j_sqrt(theta2);
+        jet4 costheta = j_cos(theta);
+        jet4 sintheta = j_sin(theta);
+        jet4 theta_inv = j_div(j_const(1.0), theta);
+        jet4 w[3] = { j_mul(aa[0], theta_inv), j_mul(aa[1], theta_inv), j_mul(aa[2], theta_inv) };
+        jet4 wxp[3] = {
+            j_sub(j_mul(w[1], pt[2]), j_mul(w[2], pt[1])),
+            j_sub(j_mul(w[2], pt[0]), j_mul(w[0], pt[2])),
+            j_sub(j_mul(w[0], pt[1]), j_mul(w[1], pt[0])) };
+        jet4 tmp = j_mul(j_add(j_add(j_mul(w[0], pt[0]), j_mul(w[1], pt[1])), j_mul(w[2], pt[2])),
+                         j_sub(j_const(1.0), costheta));
+        for (int i = 0; i < 3; ++i)
+            out[i] = j_add(j_add(j_mul(pt[i], costheta), j_mul(wxp[i], sintheta)), j_mul(w[i], tmp));
+    } else {
+        jet4 wxp[3] = {
+            j_sub(j_mul(aa[1], pt[2]), j_mul(aa[2], pt[1])),
+            j_sub(j_mul(aa[2], pt[0]), j_mul(aa[0], pt[2])),
+            j_sub(j_mul(aa[0], pt[1]), j_mul(aa[1], pt[0])) };
+        for (int i = 0; i < 3; ++i) out[i] = j_add(pt[i], wxp[i]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R1: ReprojectionErrorArray::operator() on Jets (pnp_uncert_cpu.cpp:24-51).
+ * pose = [yaw, tx, ty, tz].  res[2], jac[2][4] (row-major).  Clamped quantities are replaced by
+ * constants, i.e. lose all their partials (z-clamp: only z; u/v clamp: the whole projected coord).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double fx, fy, cx, cy, z_min, u_min, u_max, v_min, v_max; } orc_cam;
+
+static void orc_residual_jet(const orc_cam *c, const double pose[4],
+                             double x2d, double y2d, double x3d, double y3d, double z3d,
+                             double wxx, double wyy, double res[2], double jac[8]) {
+    jet4 p[4] = { j_var(pose[0], 0), j_var(pose[1], 1), j_var(pose[2], 2), j_var(pose[3], 3) };
+    jet4 pts3d[3] = { j_const(x3d), j_const(y3d), j_const(z3d) };
+    jet4 r_vec[3] = { j_const(0.0), p[0], j_const(0.0) };
+    jet4 t[3];
+    j_angle_axis_rotate_point(r_vec, pts3d, t);
+    t[0] = j_add(t[0], p[1]);
+    t[1] = j_add(t[1], p[2]);
+    t[2] = j_add(t[2], p[3]);
+    /* std::max(a, b) == (a < b) ? b : a on the scalar parts  (pnp_uncert_cpu.cpp:36) */
+    if (t[2].a < c->z_min) t[2] = j_const(c->z_min);
+    jet4 proj_x = j_add(j_div(j_mul(j_const(c->fx), t[0]), t[2]), j_const(c->cx));
+    jet4 proj_y = j_add(j_div(j_mul(j_const(c->fy), t[1]), t[2]), j_const(c->cy));
+    if (proj_x.a < c->u_min) proj_x = j_const(c->u_min); else if (proj_x.a > c->u_max) proj_x = j_const(c->u_max);
+    if (proj_y.a < c->v_min) proj_y = j_const(c->v_min); else if (proj_y.a > c->v_max) proj_y = j_const(c->v_max);
+    jet4 dx = j_sub(proj_x, j_const(x2d));
+    jet4 dy = j_sub(proj_y, j_const(y2d));
+    jet4 r0 = j_mul(j_const(wxx), dx);
+    jet4 r1 = j_mul(j_const(wyy), dy);
+    res[0] = r0.a; res[1] = r1.a;
+    for (int i = 0; i < 4; ++i) { jac[i] = r0.v[i]; jac[4 + i] = r1.v[i]; }
+}
+
+/* exported for the golden-vector tests */
+void orc_residual_jacobian(const double *K, const double *clips, const double *pose,
+                           const double *pts2d, const double *pts3d, const double *wgt2d, int pn,
+                           double *res /*pn,2*/, double *jac /*pn,2,4*/) {
+    orc_cam c = { K[0], K[4], K[2], K[5], clips[0], clips[1], clips[2], clips[3], clips[4] };
+    for (int i = 0; i < pn; ++i)
+        orc_residual_jet(&c, pose, pts2d[2 * i], pts2d[2 * i + 1], pts3d[3 * i], pts3d[3 * i + 1],
+                         pts3d[3 * i + 2], wgt2d[2 * i], wgt2d[2 * i + 1], res + 2 * i, jac + 8 * i);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Problem evaluation: cost = 1/2 sum r^2, g = J^T r, H = J^T J  (what Ceres' evaluator hands the
+ * minimizer).  Returns 0 when anything is non-finite (Ceres: "evaluation failed").
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    orc_cam cam; int pn;
+    const double *pts2d, *pts3d, *wgt2d;
+} orc_problem;
+
+static int orc_eval(const orc_problem *pb, const double x[4], double *cost, double g[4], double H[16]) {
+    double c = 0.0; double gg[4] = {0, 0, 0, 0}; double HH[16]; memset(HH, 0, sizeof HH);
+    for (int i = 0; i < pb->pn; ++i) {
+        double r[2], J[8];
+        orc_residual_jet(&pb->cam, x, pb->pts2d[2 * i], pb->pts2d[2 * i + 1], pb->pts3d[3 * i],
+                         pb->pts3d[3 * i + 1], pb->pts3d[3 * i + 2], pb->wgt2d[2 * i], pb->wgt2d[2 * i + 1], r, J);
+        c += r[0] * r[0] + r[1] * r[1];
+        if (g) for (int a = 0; a < 4; ++a) {
+            gg[a] += J[a] * r[0] + J[4 + a] * r[1];
+            for (int b = 0; b < 4; ++b) HH[4 * a + b] += J[a] * J[b] + J[4 + a] * J[4 + b];
+        }
+    }
+    *cost = 0.5 * c;
+    int ok = isfinite(*cost);
+    if (g) { for (int a = 0; a < 4; ++a) { g[a] = gg[a]; ok = ok && isfinite(gg[a]); }
+             for (int a = 0; a < 16; ++a) { H[a] = HH[a]; ok = ok && isfinite(HH[a]); } }
+    return ok;
+}
+
+/* Cholesky solve of a symmetric n x n (n<=5) system, row-major full storage. 0 on non-PD. */
+static int orc_chol_solve(int n, const double *A, const double *b, double *x) {
+    double L[25];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; ++k) s = fma(-L[i * n + k], L[j * n + k], s);
+            if (i == j) { if (!(s > 0.0) || !isfinite(s)) return 0; L[i * n + i] = sqrt(s); }
+            else L[i * n + j] = s / L[j * n + j];
+        }
+    double y[5];
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s = fma(-L[i * n + k], y[k], s); y[i] = s / L[i * n + i]; }
+    for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s = fma(-L[k * n + i], x[k], s); x[i] = s / L[i * n + i]; }
+    return 1;
+}
+
+/* inverse of SPD 4x4 via Cholesky (column by column). 0 on failure. */
+static int orc_spd_inverse4(const double H[16], double inv[16]) {
+    for (int c = 0; c < 4; ++c) {
+        double e[4] = {0, 0, 0, 0}, x[4]; e[c] = 1.0;
+        if (!orc_chol_solve(4, H, e, x)) return 0;
+        for (int r = 0; r < 4; ++r) inv[4 * r + c] = x[r];
+    }
+    for (int i = 0; i < 16; ++i) if (!isfinite(inv[i])) return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R3: Ceres 1.14 trust-region Levenberg-Marquardt, restated (defaults; only
+ * linear_solver_type=DENSE_QR is set by the reference, pnp_uncert_cpu.cpp:270-271).
+ * The dense-QR solve of  min ||[J;D] y - [r;0]||  is done through its normal equations
+ * (J^T J + D^2) y = J^T r  (mathematically identical; 4x4, Jacobi-scaled, fp64).
+ * ---------------------------------------------------------------------------------------- */
+enum { ORC_CONVERGENCE = 0, ORC_NO_CONVERGENCE = 1, ORC_FAILURE = 2 };
+enum { ORC_WHY_GRADIENT = 1, ORC_WHY_PARAMETER = 2, ORC_WHY_FUNCTION = 3, ORC_WHY_MAXITER = 4,
+       ORC_WHY_MINRADIUS = 5, ORC_WHY_INVALID = 6, ORC_WHY_EVALFAIL = 7 };
+
+typedef struct {
+    int termination, why, num_iterations /* loop passes executed (step attempts) */;
+    int num_successful;
+    double initial_cost, final_cost, radius;
+} orc_lm_summary;
+
+static void orc_lm(const orc_problem *pb, const double init[4], double out[4], orc_lm_summary *sm) {
+    const int    max_num_iterations = 50;
+    const double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
+    const double min_relative_decrease = 1e-3;
+    const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const int    max_consecutive_invalid = 5;
+
+    double x[4]; memcpy(x, init, sizeof x); memcpy(out, init, sizeof x);
+    double cost, g[4], H[16];
+    double radius = initial_radius, decrease_factor = 2.0;
+    memset(sm, 0, sizeof *sm); sm->radius = radius;
+
+    /* IterationZero */
+    if (!orc_eval(pb, x, &cost, g, H)) { sm->termination = ORC_FAILURE; sm->why = ORC_WHY_EVALFAIL; sm->radius = 0.0; return; }
+    sm->initial_cost = sm->final_cost = cost;
+    double scale[4];
+    for (int j = 0; j < 4; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[5 * j]));   /* jacobi_scaling, from the initial J */
+    double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    int last_successful = 1;        /* iteration 0 counts as successful (IterationZero sets it) */
+    int iteration = 0, invalid_run = 0;
+
+    for (;;) {
+        /* FinalizeIterationAndCheckIfMinimizerCanContinue (parameters are committed here) */
+        if (last_successful) { memcpy(out, x, sizeof x); sm->final_cost = cost; }
+        sm->radius = radius; sm->num_iterations = iteration;
+        if (iteration >= max_num_iterations) { sm->termination = ORC_NO_CONVERGENCE; sm->why = ORC_WHY_MAXITER; return; }
+        if (last_successful) {
+            double gmax = 0.0; for (int j = 0; j < 4; ++j) if (fabs(g[j]) > gmax) gmax = fabs(g[j]);
+            if (gmax <= gradient_tolerance) { sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_GRADIENT; return; }
+        }
+        if (radius <= min_radius) { sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_MINRADIUS; return; }
+
+        ++iteration; last_successful = 0;
+        /* ComputeTrustRegionStep — LevenbergMarquardtStrategy::ComputeStep on the scaled Jacobian */
+        double Hs[16], gs[4], A[16], D2[4], y[4], step[4];
+        for (int a = 0; a < 4; ++a) { gs[a] = g[a] * scale[a]; for (int b = 0; b < 4; ++b) Hs[4 * a + b] = H[4 * a + b] * scale[a] * scale[b]; }
+        for (int j = 0; j < 4; ++j) {
+            double d = Hs[5 * j]; d = fmin(fmax(d, min_lm_diagonal), max_lm_diagonal);
+            D2[j] = d / radius;                       /* lm_diagonal = sqrt(diagonal/radius); D^2 enters the normal eqs */
+        }
+        memcpy(A, Hs, sizeof A); for (int j = 0; j < 4; ++j) A[5 * j] += D2[j];
+        int step_ok = orc_chol_solve(4, A, gs, y);
+        if (step_ok) for (int j = 0; j < 4; ++j) { step[j] = -y[j]; if (!isfinite(step[j])) step_ok = 0; }
+        double model_cost_change = 0.0;
+        if (step_ok) {
+            /* model_cost_change = -(J s)^T (r + J s / 2) = -(s^T gs + 1/2 s^T Hs s) */
+            double sg = 0.0, sHs = 0.0;
+            for (int a = 0; a < 4; ++a) { sg += step[a] * gs[a]; double t = 0.0; for (int b = 0; b < 4; ++b) t += Hs[4 * a + b] * step[b]; sHs += step[a] * t; }
+            model_cost_change = -(sg + 0.5 * sHs);
+            step_ok = (model_cost_change > 0.0);
+        }
+        if (!step_ok) {                                  /* HandleInvalidStep */
+            if (++invalid_run >= max_consecutive_invalid) { sm->termination = ORC_FAILURE; sm->why = ORC_WHY_INVALID; sm->num_iterations = iteration; return; }
+            radius *= 0.5;                               /* StepIsInvalid */
+            continue;
+        }
+        invalid_run = 0;
+        double delta[4], cand[4];
+        for (int j = 0; j < 4; ++j) { delta[j] = step[j] * scale[j]; cand[j] = x[j] + delta[j]; }
+        double cand_cost, cg[4], cH[16];
+        if (!orc_eval(pb, cand, &cand_cost, cg, cH) ) cand_cost = DBL_MAX;   /* ComputeCandidatePointAndEvaluateCost */
+        /* ParameterToleranceReached — uses ||x - candidate|| */
+        double step_norm = 0.0; for (int j = 0; j < 4; ++j) { double d = x[j] - cand[j]; step_norm += d * d; } step_norm = sqrt(step_norm);
+        if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) {
+            sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_PARAMETER; sm->num_iterations = iteration; return; }
+        /* FunctionToleranceReached */
+        double cost_change = cost - cand_cost;
+        if (fabs(cost_change) <= function_tolerance * cost) {
+            sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_FUNCTION; sm->num_iterations = iteration; return; }
+        double relative_decrease = cost_change / model_cost_change;        /* monotonic StepQuality */
+        if (relative_decrease > min_relative_decrease) {                   /* HandleSuccessfulStep */
+            memcpy(x, cand, sizeof x); x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+            cost = cand_cost; memcpy(g, cg, sizeof g); memcpy(H, cH, sizeof H);
+            last_successful = 1; ++sm->num_successful;
+            double t = 2.0 * relative_decrease - 1.0;                      /* StepAccepted */
+            radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+            radius = fmin(max_radius, radius);
+            decrease_factor = 2.0;
+        } else {                                                           /* HandleUnsuccessfulStep / StepRejected */
+            radius = radius / decrease_factor; decrease_factor *= 2.0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The reference's C entry point, same signature (src/ext.h:1-13, pnp_uncert_cpu.cpp:245-292).
+ * result_cov (optional) = Ceres Covariance of the pose block = (J^T J)^-1 with the *Ceres*
+ * Jacobian at the solution; failure (rank deficient) -> *result_val = 0, result_cov untouched.
+ * ---------------------------------------------------------------------------------------- */
+void orc_pnp_uncert_diag(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose,
+                         int *result_val, double *result_pose, double *result_cov, double *result_tr,
+                         int pn, double *clips, double *diag /* 6: iters, why, termination, init_cost, final_cost, n_success */) {
+    orc_problem pb;
+    pb.cam.fx = K[0]; pb.cam.fy = K[4]; pb.cam.cx = K[2]; pb.cam.cy = K[5];
+    pb.cam.z_min = clips[0]; pb.cam.u_min = clips[1]; pb.cam.u_max = clips[2]; pb.cam.v_min = clips[3]; pb.cam.v_max = clips[4];
+    pb.pn = pn; pb.pts2d = pts2d; pb.pts3d = pts3d; pb.wgt2d = wgt2d;
+    orc_lm_summary sm;
+    orc_lm(&pb, init_pose, result_pose, &sm);
+    *result_val = (sm.termination == ORC_CONVERGENCE || sm.termination == ORC_NO_CONVERGENCE) ? 1 : 0;
+    *result_tr = sm.radius;
+    if (diag) { diag[0] = sm.num_iterations; diag[1] = sm.why; diag[2] = sm.termination; diag[3] = sm.initial_cost; diag[4] = sm.final_cost; diag[5] = sm.num_successful; }
+    if (*result_val && result_cov) {
+        double cost, g[4], H[16], inv[16];
+        int ok = orc_eval(&pb, result_pose, &cost, g, H) && orc_spd_inverse4(H, inv);
+        *result_val = ok ? 1 : 0;
+        if (ok) memcpy(result_cov, inv, sizeof inv);
+    }
+}
+
+void orc_pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose,
+                    int *result_val, double *result_pose, double *result_cov, double *result_tr,
+                    int pn, double *clips) {
+    orc_pnp_uncert_diag(pts2d, pts3d, wgt2d, K, init_pose, result_val, result_pose, result_cov, result_tr, pn, clips, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R2/R7: torch-semantics Jacobian and approx Hessian (jacobian.py:4-98, hessian.py:67-87), one object.
+ * Full 2x3 upper K is honoured (forward_proj multiplies by cam_mats, :20-26); depth = 3rd row of
+ * K R X + K t.  zero_mask = z_clip | uv_clip(per axis) | outlier  (jacobian.py:52-59).
+ * Column order [yaw, tx, ty, tz]; rows point-major [u0, v0, u1, v1, ...].
+ * jac (pn,2,4) and err (pn,2) may be NULL.  All fp64.
+ * ---------------------------------------------------------------------------------------- */
+void orc_torch_jacobian(const double *K /*9*/, double z_min, const double *u_range, const double *v_range,
+                        double yaw, const double *t, const double *pts2d, const double *pts3d,
+                        const double *istd, const uint8_t *inlier /*nullable*/, int pn,
+                        double *jac, double *err, double *H /*16*/) {
+    const double s = sin(yaw), c = cos(yaw);
+    /* k_r = K * R_y,  R_y = [[c,0,s],[0,1,0],[-s,0,c]] ;  k_t = K t */
+    double kr[9], kt[3];
+    for (int r = 0; r < 3; ++r) {
+        kr[3 * r + 0] = K[3 * r + 0] * c - K[3 * r + 2] * s;
+        kr[3 * r + 1] = K[3 * r + 1];
+        kr[3 * r + 2] = K[3 * r + 0] * s + K[3 * r + 2] * c;
+        kt[r] = K[3 * r + 0] * t[0] + K[3 * r + 1] * t[1] + K[3 * r + 2] * t[2];
+    }
+    /* jac_yaw_m1 = K[0:2,[0,2]] * [[-s, c],[-c,-s]]  (jacobian.py:74-81) */
+    const double m1[4] = { K[0] * (-s) + K[2] * (-c), K[0] * c + K[2] * (-s),
+                           K[3] * (-s) + K[5] * (-c), K[3] * c + K[5] * (-s) };
+    double HH[16]; memset(HH, 0, sizeof HH);
+    for (int i = 0; i < pn; ++i) {
+        const double X = pts3d[3 * i], Y = pts3d[3 * i + 1], Z = pts3d[3 * i + 2];
+        double uvz[3];
+        for (int r = 0; r < 3; ++r) uvz[r] = kr[3 * r] * X + kr[3 * r + 1] * Y + kr[3 * r + 2] * Z + kt[r];
+        double z = uvz[2]; const int zclip = z < z_min; if (zclip) z = z_min;
+        double uv[2] = { uvz[0] / z, uvz[1] / z };
+        const double lb[2] = { u_range[0], v_range[0] }, ub[2] = { u_range[1], v_range[1] };
+        int clip[2];
+        for (int a = 0; a < 2; ++a) { clip[a] = (uv[a] < lb[a]) || (uv[a] > ub[a]); uv[a] = fmax(lb[a], fmin(ub[a], uv[a])); }
+        const int outl = inlier ? !inlier[i] : 0;
+        double J[8];
+        for (int a = 0; a < 2; ++a) {
+            const double w = istd[2 * i + a];
+            const int zero = zclip || clip[a] || outl;
+            /* jac_t_vec = [K[a,0], K[a,1], K[a,2]-uv[a]] / z * istd */
+            double jt0 = K[3 * a + 0] / z, jt1 = K[3 * a + 1] / z, jt2 = (K[3 * a + 2] - uv[a]) / z;
+            /* jac_yaw = ((m1[a,:] + uv[a]*[c,s]) . [X, Z]) / z * istd */
+            double jy = ((m1[2 * a] + uv[a] * c) * X + (m1[2 * a + 1] + uv[a] * s) * Z) / z;
+            J[4 * a + 0] = zero ? 0.0 : jy * w;
+            J[4 * a + 1] = zero ? 0.0 : jt0 * w;
+            J[4 * a + 2] = zero ? 0.0 : jt1 * w;
+            J[4 * a + 3] = zero ? 0.0 : jt2 * w;
+            if (err) err[2 * i + a] = (uv[a] - pts2d[2 * i + a]) * w;   /* error is NOT masked (jacobian.py:163-165) */
+        }
+        if (jac) memcpy(jac + 8 * i, J, sizeof J);
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) HH[4 * a + b] += J[a] * J[b] + J[4 + a] * J[4 + b];
+    }
+    if (H) memcpy(H, HH, sizeof HH);
+}
+
+/* R6: pose_cov = inverse(h); singular -> identity + invalid (the per-object reading of pnp_uncert.py:77-85) */
+int orc_pose_cov(const double H[16], double cov[16]) {
+    if (orc_spd_inverse4(H, cov)) return 1;
+    for (int i = 0; i < 16; ++i) cov[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K0: deterministic initialiser + consensus inlier selection (this repo's replacement for
+ * cv2.solvePnPRansac(EPNP, 30 iters) / cv2.solvePnP(EPNP), pnp_uncert_cpu.py:35-58).  Spec in DESIGN.md §K0.
+ *   - candidates: the istd-inlier set (mask0), listed in ascending point index
+ *   - hypothesis h = 0..n_hyp-1: 5 points, one per fifth of the candidate list (stratified),
+ *     picked by a counter-based hash; linear 4-DoF solve (5x5 normal eqs in (cos,sin,tx,ty,tz)),
+ *     normalise (cos,sin), re-solve t (3x3) — fp64, fixed operation order, explicit fma
+ *   - consensus of every hypothesis over the candidates in fp32 with a fixed operation order:
+ *     |fx X - (u-cx) Z|^2 + |fy Y - (v-cy) Z|^2 <= (thr Z)^2  and  Z > 0
+ *   - best = first maximum; fewer than 5 consensus points -> failure (ret False, like RANSAC)
+ *   - refit on the consensus set with the same linear solver (fp64), yaw0 = atan2(sin, cos)
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_K0_SEED 0x9E3779B9u
+static uint32_t orc_hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+
+typedef struct { double fx, fy, cx, cy; } orc_k4;
+
+/* accumulate one point into the 5x5 system; n5: upper triangle row-major (15), m5: rhs (5) */
+static void orc_lin5_add(const orc_k4 *k, float u, float v, float x, float y, float z, double n5[15], double m5[5]) {
+    const double a = (double)u - k->cx, b = (double)v - k->cy;
+    const double X = x, Y = y, Z = z;
+    const double ru[5] = { fma(a, Z, -(k->fx * X)), fma(-a, X, -(k->fx * Z)), -k->fx, 0.0, a };
+    const double rv[5] = { b * Z, -(b * X), 0.0, -k->fy, b };
+    const double rhs_v = k->fy * Y;
+    int q = 0;
+    for (int i = 0; i < 5; ++i) {
+        for (int j = i; j < 5; ++j, ++q) n5[q] = fma(rv[i], rv[j], fma(ru[i], ru[j], n5[q]));
+        m5[i] = fma(rv[i], rhs_v, m5[i]);
+    }
+}
+/* accumulate one point into the 3x3 translation system given unit (c,s) */
+static void orc_lin3_add(const orc_k4 *k, double c, double s, float u, float v, float x, float y, float z, double n3[4], double m3[3]) {
+    const double a = (double)u - k->cx, b = (double)v - k->cy;
+    const double X = x, Y = y, Z = z;
+    const double Xr = fma(c, X, s * Z), Zr = fma(c, Z, -(s * X));
+    const double bu = fma(k->fx, Xr, -(a * Zr));       /* -fx tx + a tz = fx Xr - a Zr */
+    const double bv = fma(k->fy, Y, -(b * Zr));        /* -fy ty + b tz = fy Y  - b Zr */
+    /* n3 = { sum fx^2 (count), sum a, sum b, sum a^2+b^2 } – the structurally non-zero sums */
+    n3[0] += 1.0; n3[1] += a; n3[2] += b; n3[3] = fma(b, b, fma(a, a, n3[3]));
+    m3[0] = fma(-k->fx, bu, m3[0]); m3[1] = fma(-k->fy, bv, m3[1]); m3[2] = fma(b, bv, fma(a, bu, m3[2]));
+}
+static int orc_lin5_solve(const double n5[15], const double m5[5], double *c, double *s) {
+    double A[25], th[5]; int q = 0;
+    for (int i = 0; i < 5; ++i) for (int j = i; j < 5; ++j, ++q) A[5 * i + j] = A[5 * j + i] = n5[q];
+    if (!orc_chol_solve(5, A, m5, th)) return 0;
+    const double rho2 = fma(th[0], th[0], th[1] * th[1]);
+    if (!(rho2 > 1e-12) || !isfinite(rho2)) return 0;
+    const double inv = 1.0 / sqrt(rho2);
+    *c = th[0] * inv; *s = th[1] * inv;
+    return 1;
+}
+static int orc_lin3_solve(const orc_k4 *k, const double n3[4], const double m3[3], double t[3]) {
+    const double A[9] = { k->fx * k->fx * n3[0], 0.0, -k->fx * n3[1],
+                          0.0, k->fy * k->fy * n3[0], -k->fy * n3[2],
+                          -k->fx * n3[1], -k->fy * n3[2], n3[3] };
+    if (!orc_chol_solve(3, A, m3, t)) return 0;
+    return isfinite(t[0]) && isfinite(t[1]) && isfinite(t[2]);
+}
+static int orc_consensus(const float hyp[5], float fx, float fy, float a, float b, float x, float y, float z, float thr) {
+    const float c = hyp[0], s = hyp[1];
+    const float Xc = fmaf(c, x, fmaf(s, z, hyp[2]));
+    const float Zc = fmaf(c, z, fmaf(-s, x, hyp[4]));
+    const float Yc = y + hyp[3];
+    const float eu = fmaf(-a, Zc, fx * Xc);
+    const float ev = fmaf(-b, Zc, fy * Yc);
+    const float e2 = fmaf(eu, eu, ev * ev);
+    const float lim = thr * Zc;
+    return (Zc > 0.0f) && (e2 <= lim * lim);
+}
+
+/* returns 1 on success.  mask: in = candidates (mask0), out = consensus set (if ransac) . */
+int orc_k0_init(const float *x2d /*pn,2*/, const float *x3d /*pn,3*/, uint8_t *mask, int pn,
+                const float *K /*9, f32*/, int use_ransac, float thr, int n_hyp,
+                double init_pose[4], int *best_hyp, int *best_count) {
+    const float fxf = K[0], fyf = K[4], cxf = K[2], cyf = K[5];
+    const orc_k4 k = { (double)fxf, (double)fyf, (double)cxf, (double)cyf };
+    int *list = (int *)malloc(sizeof(int) * (size_t)(pn > 0 ? pn : 1)); int n = 0;
+    for (int p = 0; p < pn; ++p) if (mask[p]) list[n++] = p;
+    if (best_hyp) *best_hyp = -1; if (best_count) *best_count = n;
+    int ok = 1;
+    if (use_ransac) {
+        if (n_hyp > 64) n_hyp = 64;
+        float hyp[64][5]; int valid[64];
+        for (int h = 0; h < n_hyp; ++h) {
+            valid[h] = 0;
+            if (n < 5) continue;
+            double n5[15], m5[5], n3[4], m3[3], c, s, t[3]; int idx[5];
+            memset(n5, 0, sizeof n5); memset(m5, 0, sizeof m5); memset(n3, 0, sizeof n3); memset(m3, 0, sizeof m3);
+            for (int j = 0; j < 5; ++j) {
+                const uint32_t lo = (uint32_t)(((uint64_t)j * (uint64_t)n) / 5u), hi = (uint32_t)(((uint64_t)(j + 1) * (uint64_t)n) / 5u);
+                const uint32_t r = lo + (uint32_t)(((uint64_t)orc_hash32(ORC_K0_SEED + (uint32_t)h * 8u + (uint32_t)j) * (uint64_t)(hi - lo)) >> 32);
+                idx[j] = list[r];
+                const int p = idx[j];
+                orc_lin5_add(&k, x2d[2 * p], x2d[2 * p + 1], x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], n5, m5);
+            }
+            if (!orc_lin5_solve(n5, m5, &c, &s)) continue;
+            for (int j = 0; j < 5; ++j) { const int p = idx[j];
+                orc_lin3_add(&k, c, s, x2d[2 * p], x2d[2 * p + 1], x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], n3, m3); }
+            if (!orc_lin3_solve(&k, n3, m3, t)) continue;
+            hyp[h][0] = (float)c; hyp[h][1] = (float)s; hyp[h][2] = (float)t[0]; hyp[h][3] = (float)t[1]; hyp[h][4] = (float)t[2];
+            valid[h] = 1;
+        }
+        int best = -1, bestc = 0;
+        for (int h = 0; h < n_hyp; ++h) {
+            if (!valid[h]) continue;
+            int cnt = 0;
+            for (int q = 0; q < n; ++q) { const int p = list[q];
+                cnt += orc_consensus(hyp[h], fxf, fyf, x2d[2 * p] - cxf, x2d[2 * p + 1] - cyf, x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], thr); }
+            if (cnt > bestc) { bestc = cnt; best = h; }
+        }
+        if (best_hyp) *best_hyp = best; if (best_count) *best_count = bestc;
+        if (best < 0 || bestc < 5) ok = 0;
+        else {
+            int m = 0;
+            for (int q = 0; q < n; ++q) { const int p = list[q];
+                const int in = orc_consensus(hyp[best], fxf, fyf, x2d[2 * p] - cxf, x2d[2 * p + 1] - cyf, x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], thr);
+                mask[p] = (uint8_t)in; if (in) list[m++] = p; }
+            n = m;
+        }
+    }
+    if (ok) {   /* refit on the final set (the analogue of the final EPnP on the inliers) */
+        double n5[15], m5[5], n3[4], m3[3], c, s, t[3];
+        memset(n5, 0, sizeof n5); memset(m5, 0, sizeof m5); memset(n3, 0, sizeof n3); memset(m3, 0, sizeof m3);
+        for (int q = 0; q < n; ++q) { const int p = list[q]; orc_lin5_add(&k, x2d[2 * p], x2d[2 * p + 1], x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], n5, m5); }
+        ok = orc_lin5_solve(n5, m5, &c, &s);
+        if (ok) { for (int q = 0; q < n; ++q) { const int p = list[q]; orc_lin3_add(&k, c, s, x2d[2 * p], x2d[2 * p + 1], x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], n3, m3); }
+                  ok = orc_lin3_solve(&k, n3, m3, t); }
+        if (ok) { init_pose[0] = atan2(s, c); init_pose[1] = t[0]; init_pose[2] = t[1]; init_pose[3] = t[2]; }
+    }
+    free(list);
+    return ok;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R5 + R6 for a batch: per object  mask0 -> (count>4 ? subset : all) -> K0 (or given init) ->
+ * LM on inliers (inlier_opt_only) -> float32 pose -> torch-semantics J^T J on ALL points masked by
+ * the final inlier mask -> inverse.  (pnp_uncert_cpu.py:11-125, pnp_uncert.py:45-85.)
+ * Inputs contiguous float32 (B,P,2),(B,P,2),(B,P,3); K (Kb,9), ranges (Rb,2) broadcast when Kb/Rb==1.
+ * mask: in = istd inlier mask from the host (numpy) stage, out = final inlier mask.
+ * ---------------------------------------------------------------------------------------- */
+static void orc_one_object(const float *x2d, const float *istd, const float *x3d, const float *K,
+                           const float *ur, const float *vr, const float *thr, const double *init,
+                           int pn, double z_min, int inlier_opt_only, int n_hyp,
+                           uint8_t *mask, uint8_t *valid, float *pose, float *cov, float *tr, float *diag) {
+    int cnt = 0; for (int p = 0; p < pn; ++p) cnt += mask[p] ? 1 : 0;
+    if (!(cnt > 4)) { memset(mask, 1, (size_t)pn); }                       /* pnp_uncert_cpu.py:23-32 */
+    double init_pose[4] = {0, 0, 0, 0}; int ok, bh = -1, bc = 0;
+    if (init) { memcpy(init_pose, init, sizeof init_pose); ok = 1; }
+    else ok = orc_k0_init(x2d, x3d, mask, pn, K, thr != NULL, thr ? *thr : 0.0f, n_hyp, init_pose, &bh, &bc);
+    double res_pose[4] = {0, 0, 0, 0}, res_tr = 0.0; int res_val = 0; double dg[6] = {0, 0, 0, 0, 0, 0};
+    if (ok) {
+        /* gather what LM sees, cast to float64 (pnp_uncert_cpu.py:62-81) */
+        double *b2 = (double *)malloc(sizeof(double) * (size_t)pn * 7); double *b3 = b2 + 2 * (size_t)pn, *bw = b3 + 3 * (size_t)pn;
+        int m = 0;
+        for (int p = 0; p < pn; ++p) if (!inlier_opt_only || mask[p]) {
+            b2[2 * m] = x2d[2 * p]; b2[2 * m + 1] = x2d[2 * p + 1];
+            b3[3 * m] = x3d[3 * p]; b3[3 * m + 1] = x3d[3 * p + 1]; b3[3 * m + 2] = x3d[3 * p + 2];
+            bw[2 * m] = istd[2 * p]; bw[2 * m + 1] = istd[2 * p + 1]; ++m; }
+        double Kd[9]; for (int i = 0; i < 9; ++i) Kd[i] = K[i];
+        double clips[5] = { z_min, ur[0], ur[1], vr[0], vr[1] };
+        orc_pnp_uncert_diag(b2, b3, bw, Kd, init_pose, &res_val, res_pose, NULL, &res_tr, m, clips, dg);
+        free(b2);
+    }
+    /* float32 outputs (pnp_uncert_cpu.py:108-125) */
+    for (int j = 0; j < 4; ++j) pose[j] = ok ? (float)res_pose[j] : 0.0f;
+    *tr = ok ? (float)res_tr : 0.0f;
+    *valid = (uint8_t)(ok && res_val);
+    if (diag) { diag[0] = (float)dg[0]; diag[1] = (float)dg[4]; diag[2] = (float)dg[1]; diag[3] = (float)bc; }
+    /* covariance at the float32 pose, all points, final mask (pnp_uncert.py:71-85) */
+    {
+        double *d2 = (double *)malloc(sizeof(double) * (size_t)pn * 7); double *d3 = d2 + 2 * (size_t)pn, *dw = d3 + 3 * (size_t)pn;
+        for (int i = 0; i < 2 * pn; ++i) { d2[i] = x2d[i]; dw[i] = istd[i]; }
+        for (int i = 0; i < 3 * pn; ++i) d3[i] = x3d[i];
+        double Kd[9]; for (int i = 0; i < 9; ++i) Kd[i] = K[i];
+        double urd[2] = { ur[0], ur[1] }, vrd[2] = { vr[0], vr[1] }, td[3] = { pose[1], pose[2], pose[3] }, H[16], C[16];
+        orc_torch_jacobian(Kd, z_min, urd, vrd, (double)pose[0], td, d2, d3, dw, mask, pn, NULL, NULL, H);
+        if (!orc_pose_cov(H, C)) *valid = 0;
+        for (int i = 0; i < 16; ++i) cov[i] = (float)C[i];
+        free(d2);
+    }
+}
+
+void orc_u2d_pnp_batch(const float *x2d, const float *istd, const float *x3d,
+                       const float *K, int Kb, const float *u_range, const float *v_range, int Rb,
+                       const float *ransac_thr /*nullable (B)*/, const double *init_pose /*nullable (B,4)*/,
+                       int B, int P, double z_min, int inlier_opt_only, int n_hyp, int num_threads,
+                       uint8_t *mask /*B,P in/out*/, uint8_t *valid /*B*/, float *pose /*B,4*/,
+                       float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/) {
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#pragma omp parallel for schedule(dynamic, 4) if (num_threads != 1)
+#endif
+    for (int b = 0; b < B; ++b) {
+        orc_one_object(x2d + (size_t)b * P * 2, istd + (size_t)b * P * 2, x3d + (size_t)b * P * 3,
+                       K + (Kb == 1 ? 0 : (size_t)b * 9), u_range + (Rb == 1 ? 0 : (size_t)b * 2), v_range + (Rb == 1 ? 0 : (size_t)b * 2),
+                       ransac_thr ? ransac_thr + b : NULL, init_pose ? init_pose + (size_t)b * 4 : NULL,
+                       P, z_min, inlier_opt_only, n_hyp,
+                       mask + (size_t)b * P, valid + b, pose + (size_t)b * 4, cov + (size_t)b * 16, tr + b, diag ? diag + (size_t)b * 4 : NULL);
+    }
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
