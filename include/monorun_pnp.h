@@ -123,8 +123,8 @@ int mr_noc_decode_batched(
     int B, int num_classes, int class_agnostic, int h, int w,
     const float *dim_means /* (C,3) */, const float *dim_stds /* (C,3) */,
     const float *noc_means /* 3 */, const float *noc_stds /* 3 */,
-    float proj_scaling_denominator, float ref_focal_y, float epistemic_std_gain,
-    float std_scale, float ransac_thres_ratio,
+    double proj_scaling_denominator /* ref_length*ref_focal_y*target_std, e.g. 173.28 */, double ref_focal_y, double epistemic_std_gain,
+    float std_scale, float ransac_thres_ratio /* <0: ransac_thr not written */,
     float *coords_2d, float *coords_2d_istd, float *coords_3d,
     float *dims, float *dims_var, float *ransac_thr,
     void *stream);

@@ -76,7 +76,7 @@ def load():
         lib.mr_noc_decode_batched.restype = i32
         lib.mr_noc_decode_batched.argtypes = [
             vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
-            vp, vp, vp, vp, f32, f32, f32, f32, f32,
+            vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
             vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib

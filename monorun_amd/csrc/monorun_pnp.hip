@@ -46,6 +46,7 @@ struct PnpArgs {
     double z_min; float istd_thres; int inlier_opt_only; int flags; int mean_mode;
     uint8_t *valid; float *pose; float *cov; float *tr; uint8_t *mask; float *diag;
     double *pose64, *cov64, *tr64;            // legacy per-object ABI outputs (nullable)
+    unsigned long long *stamps;               // debug: (B,10) s_memtime stamps + HW_ID + XCC_ID per stage (nullable)
     PairwisePlan plan;
 };
 
@@ -266,7 +267,7 @@ __device__ __forceinline__ void eval_point(const Cam &k, double c, double s, dou
 struct Eval { double cost; double g[4]; double H[16]; bool ok; };
 
 template <int WPO, typename S>
-__device__ __forceinline__ void evaluate(const Cam &k, const double (&x)[4], int Ppad, bool use_mask,
+__device__ __forceinline__ void evaluate(const Cam &k, const double (&x)[4], int P, int Ppad, bool use_mask,
                                          const S *su, const S *sv, const S *swu, const S *swv,
                                          const S *sx, const S *sy, const S *sz, const uint8_t *smask,
                                          double *red, Eval &e) {
@@ -278,10 +279,11 @@ __device__ __forceinline__ void evaluate(const Cam &k, const double (&x)[4], int
     for (int i = 0; i < kAcc; ++i) acc[i] = 0.0;
 #pragma unroll 2
     for (int p = threadIdx.x; p < Ppad; p += NT) {
-        const bool m = use_mask ? (smask[p] != 0) : true;
-        const double wu = m ? (double)swu[p] : 0.0, wv = m ? (double)swv[p] : 0.0;
-        eval_point(k, cs, sn, x[1], x[2], x[3], (double)su[p], (double)sv[p], wu, wv,
-                   (double)sx[p], (double)sy[p], (double)sz[p], acc);
+        // points outside the inlier set are not part of the problem at all (pnp_uncert_cpu.py:62-66):
+        // skip them instead of zero-weighting them so that a NaN correspondence there cannot poison the sums
+        if (use_mask ? (smask[p] != 0) : (p < P))
+            eval_point(k, cs, sn, x[1], x[2], x[3], (double)su[p], (double)sv[p], (double)swu[p], (double)swv[p],
+                       (double)sx[p], (double)sy[p], (double)sz[p], acc);
     }
     block_sum<WPO, kAcc>(acc, red);
     e.cost = 0.5 * acc[13];
@@ -305,7 +307,7 @@ struct LmResult { double x[4]; double radius; double cost; int iters; int why; b
 // linear_solver_type = DENSE_QR is set by the reference, pnp_uncert_cpu.cpp:270-271); the QR solve of
 // [J; D] y = [r; 0] is done through its (Jacobi-scaled, 4x4, fp64) normal equations.
 template <int WPO, typename S>
-__device__ void lm_solve(const Cam &k, const double (&init)[4], int Ppad, bool use_mask,
+__device__ void lm_solve(const Cam &k, const double (&init)[4], int P, int Ppad, bool use_mask,
                          const S *su, const S *sv, const S *swu, const S *swv,
                          const S *sx, const S *sy, const S *sz, const uint8_t *smask,
                          double *red, LmResult &r) {
@@ -321,7 +323,7 @@ __device__ void lm_solve(const Cam &k, const double (&init)[4], int Ppad, bool u
     r.iters = 0; r.why = 0; r.usable = false; r.radius = radius; r.cost = 0.0;
 
     Eval cur;
-    evaluate<WPO, S>(k, x, Ppad, use_mask, su, sv, swu, swv, sx, sy, sz, smask, red, cur);
+    evaluate<WPO, S>(k, x, P, Ppad, use_mask, su, sv, swu, swv, sx, sy, sz, smask, red, cur);
     if (!cur.ok) { r.why = WHY_EVALFAIL; r.radius = 0.0; return; }
     double scale[4];
 #pragma unroll
@@ -388,7 +390,7 @@ __device__ void lm_solve(const Cam &k, const double (&init)[4], int Ppad, bool u
 #pragma unroll
         for (int j = 0; j < 4; ++j) cand[j] = x[j] + step[j] * scale[j];
         Eval nxt;                                         // cost, and speculatively g/H, at the candidate
-        evaluate<WPO, S>(k, cand, Ppad, use_mask, su, sv, swu, swv, sx, sy, sz, smask, red, nxt);
+        evaluate<WPO, S>(k, cand, P, Ppad, use_mask, su, sv, swu, swv, sx, sy, sz, smask, red, nxt);
         const double cand_cost = nxt.ok ? nxt.cost : 1.7976931348623157e308;
         double step_norm = 0.0;
 #pragma unroll
@@ -454,6 +456,9 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
     const int P = a.P, Ppad = a.Ppad;
 
     extern __shared__ __align__(16) unsigned char smem[];
+#define MR_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(long long)b * 10 + (i)] = __builtin_readcyclecounter(); } while (0)
+    MR_STAMP(0);
+    if (a.stamps && tid == 0) { a.stamps[(long long)b * 10 + 8] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); a.stamps[(long long)b * 10 + 9] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
     double *red = (double *)smem;                                   // [WPO][kRedN]
     unsigned long long *sball = (unsigned long long *)(red + WPO * kRedN);   // [Ppad/64]
     S *su = (S *)(sball + ((Ppad / 64 + 1) & ~1));                  // keep the tile 16-byte aligned
@@ -481,6 +486,7 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
     cam.vmin = ld_k(a.vr, a.r_f64, ro); cam.vmax = ld_k(a.vr, a.r_f64, ro + 1);
     __syncthreads();
 
+    MR_STAMP(1);
     // ---------------------------------------------------------------- stage 1: istd inlier mask (R4)
     if (a.flags & MR_NO_ISTD_MASK) {
         for (int p = tid; p < Ppad; p += NT) smask[p] = (p < P) ? 1 : 0;
@@ -555,6 +561,7 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
         __syncthreads();
     }
 
+    MR_STAMP(2);
     // ---------------------------------------------------------------- stage 2: K0 initialiser (R5)
     double init[4] = { 0.0, 0.0, 0.0, 0.0 };
     bool init_ok = true;
@@ -625,6 +632,7 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
                 shyp[tid * 8 + 4] = ok ? (float)t[2] : nanf_;
             }
             __syncthreads();
+            MR_STAMP(3);
             // consensus of every hypothesis over the candidates (fp32, fixed operation order)
             int cnt[kHyp];
 #pragma unroll
@@ -666,6 +674,7 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
             }
             __syncthreads();
         }
+        MR_STAMP(4);
         if (init_ok) {
             // refit on the final set with the same linear solver (fp64 accumulation, tree reduction)
             double acc20[20];
@@ -707,17 +716,19 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
         }
     }
 
+    MR_STAMP(5);
     // ---------------------------------------------------------------- stage 3: LM refinement (R1,R3)
     LmResult lm;
     lm.x[0] = lm.x[1] = lm.x[2] = lm.x[3] = 0.0; lm.radius = 0.0; lm.cost = 0.0; lm.iters = 0; lm.why = WHY_K0FAIL; lm.usable = false;
     if (init_ok)
-        lm_solve<WPO, S>(cam, init, Ppad, a.inlier_opt_only != 0, su, sv, swu, swv, sx, sy, sz, smask, red, lm);
+        lm_solve<WPO, S>(cam, init, P, Ppad, a.inlier_opt_only != 0, su, sv, swu, swv, sx, sy, sz, smask, red, lm);
     const bool pose_ok = init_ok;
     float posef[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) posef[j] = pose_ok ? (float)lm.x[j] : 0.0f;       // pnp_uncert_cpu.py:108-125
     bool valid = pose_ok && lm.usable;
 
+    MR_STAMP(6);
     // ---------------------------------------------------------------- stage 4: covariance (R2,R6,R7)
     double cov[16];
     bool have_cov = false;
@@ -727,7 +738,7 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
         if (a.flags & MR_COV_CERES) {
             Eval e;
             double xe[4] = { lm.x[0], lm.x[1], lm.x[2], lm.x[3] };
-            evaluate<WPO, S>(cam, xe, Ppad, a.inlier_opt_only != 0, su, sv, swu, swv, sx, sy, sz, smask, red, e);
+            evaluate<WPO, S>(cam, xe, P, Ppad, a.inlier_opt_only != 0, su, sv, swu, swv, sx, sy, sz, smask, red, e);
 #pragma unroll
             for (int i = 0; i < 16; ++i) H[i] = e.H[i];
         } else {
@@ -765,11 +776,13 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
                 double J[8];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const double w = (zclip || cl[r] || outl) ? 0.0 : (double)(r ? swv[p] : swu[p]) * iz;
-                    J[4 * r + 0] = w * ((m1[2 * r] + uv[r] * cs) * X + (m1[2 * r + 1] + uv[r] * sn) * Z);
-                    J[4 * r + 1] = w * Kd[3 * r + 0];
-                    J[4 * r + 2] = w * Kd[3 * r + 1];
-                    J[4 * r + 3] = w * (Kd[3 * r + 2] - uv[r]);
+                    // jac[zero_mask] = 0 is an assignment (jacobian.py:70,95): select, do not multiply by zero
+                    const bool zero = zclip || cl[r] || outl;
+                    const double w = (double)(r ? swv[p] : swu[p]) * iz;
+                    J[4 * r + 0] = zero ? 0.0 : w * ((m1[2 * r] + uv[r] * cs) * X + (m1[2 * r + 1] + uv[r] * sn) * Z);
+                    J[4 * r + 1] = zero ? 0.0 : w * Kd[3 * r + 0];
+                    J[4 * r + 2] = zero ? 0.0 : w * Kd[3 * r + 1];
+                    J[4 * r + 3] = zero ? 0.0 : w * (Kd[3 * r + 2] - uv[r]);
                 }
                 int q = 0;
 #pragma unroll
@@ -795,6 +808,7 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
         }
     }
 
+    MR_STAMP(7);
     // ---------------------------------------------------------------- outputs
     if (tid == 0) {
         a.valid[b] = valid ? 1 : 0;
@@ -822,6 +836,78 @@ __global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------------
+// K2: fused NOC-head post-processing.  One thread per RoI pixel; every read of all_pred is a coalesced
+// row of the selected channel, every write a coalesced row of a channel-planar output map.
+//   R9  flip/class channel pick   fcn_noc_decoder.py:225-267  (integer indexing, bit-exact)
+//   R10 dim + NOC decode          multiclass_norm_dim_coder.py:28-36, noc_coder.py:50-73
+//   R11 log-std decode            distance_invar_proj_error_coder.py:39-60 (distance=None)
+//   R8  istd, RANSAC threshold    uncert_prop_pnp_optimizer.py:73,86-88
+//   R12 RoI bin-centre grid       roi_align(coord_2d, ..., 'avg', aligned=True), interior analytic form
+// fp32 with unfused multiply-adds, i.e. the rounding sequence of the reference's elementwise torch ops.
+struct DecodeArgs {
+    const float *all_pred; const long long *labels; const uint8_t *flip; const float *dim, *dim_var, *rois;
+    int B, C, agnostic, h, w;
+    const float *dim_means, *dim_stds; float noc_mean[3], noc_std[3];
+    float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
+    float *c2d, *istd, *c3d, *dims, *dims_var, *thr;
+};
+
+__global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lab = (int)a.labels[b];
+    const int c = a.agnostic ? 0 : lab;
+    const int f = a.flip[b] ? 1 : 0;
+    const int Cn = a.agnostic ? 1 : a.C;
+    float dm[3], dv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float sd = a.dim_stds[lab * 3 + k];
+        dm[k] = a.dim[b * 3 + k] * sd + a.dim_means[lab * 3 + k];
+        dv[k] = a.has_var ? a.dim_var[b * 3 + k] * (sd * sd) : 0.0f;
+    }
+    const float x1 = a.rois[b * 4 + 0], y1 = a.rois[b * 4 + 1], x2 = a.rois[b * 4 + 2], y2 = a.rois[b * 4 + 3];
+    const float su = (x2 - x1) / (float)a.w, sv = (y2 - y1) / (float)a.h;
+    if (p == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (a.dims) a.dims[b * 3 + k] = dm[k];
+            if (a.dims_var && a.has_var) a.dims_var[b * 3 + k] = dv[k];
+        }
+        if (a.thr) {
+            const float v_last = (y1 - 0.5f) + ((float)(a.h - 1) + 0.5f) * sv, v_first = (y1 - 0.5f) + 0.5f * sv;
+            a.thr[b] = a.ratio * (v_last - v_first);
+        }
+    }
+    if (p >= hw) return;
+    const int py = p / a.w, px = p - py * a.w;
+    const float *base = a.all_pred + (long long)b * (2 * Cn * 5) * hw;
+    const int ch_noc = f * 5 * Cn + 3 * c, ch_ls = f * 5 * Cn + 3 * Cn + 2 * c;
+    float xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float noc = base[(long long)(ch_noc + k) * hw + p];
+        const float part = noc * a.noc_std[k] + a.noc_mean[k];
+        a.c3d[((long long)b * 3 + k) * hw + p] = part * dm[k];
+        xv[k] = dv[k] * (part * part);
+    }
+    const float v2[2] = { 0.5f * (xv[0] + xv[2]), xv[1] };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float ls = base[(long long)(ch_ls + k) * hw + p];
+        float lspx;
+        if (a.has_var) lspx = 0.5f * logf((v2[k] * a.k_epi + expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
+        else lspx = ls + 0.0f;                                    // log(sd / sd)
+        a.istd[((long long)b * 2 + k) * hw + p] = expf(-lspx) / a.std_scale;
+    }
+    a.c2d[((long long)b * 2 + 0) * hw + p] = (x1 - 0.5f) + ((float)px + 0.5f) * su;
+    a.c2d[((long long)b * 2 + 1) * hw + p] = (y1 - 0.5f) + ((float)py + 0.5f) * sv;
+}
+
 size_t lds_bytes(int Ppad, int wpo, size_t store_size) {
     size_t n = 0;
     n += sizeof(double) * wpo * kRedN;
@@ -849,6 +935,7 @@ void plan_rec(PairwisePlan &pl, int off, int n, bool &ok) {
 }
 
 int g_last_hip_error = 0;
+unsigned long long *g_stamps = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
 template <typename T, int WPO>
@@ -910,6 +997,9 @@ const char *mr_pnp_error_string(int code) {
 
 int mr_pnp_last_hip_error(void) { return g_last_hip_error; }
 
+// development aid (not in the public header): device buffer of (B,8) u64 cycle stamps, or NULL to disable
+void mr_pnp_debug_set_stamps(unsigned long long *dev_ptr) { g_stamps = dev_ptr; }
+
 int mr_pnp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -938,6 +1028,7 @@ int mr_pnp_uncert_batched(
     a.ransac_thr = ransac_thr; a.init_pose = init_pose;
     a.B = B; a.P = P; a.z_min = (double)z_min; a.istd_thres = istd_thres; a.inlier_opt_only = inlier_opt_only; a.flags = flags;
     a.valid = valid; a.pose = pose; a.cov = cov; a.tr = tr_radius; a.mask = inlier_mask; a.diag = diag;
+    a.stamps = g_stamps;
     int mm = flags & MR_MEAN_MASK;
     if (mm == MR_MEAN_AUTO) mm = (istd_strides[1] == 1 && P > 1) ? MR_MEAN_PAIRWISE : MR_MEAN_SEQUENTIAL;
     a.mean_mode = mm;
@@ -954,6 +1045,37 @@ int mr_pnp_uncert_batched(
         case MR_F64: return launch_wpo<double>(a, wpo, st);
         default: return MR_ERR_UNSUPPORTED;
     }
+}
+
+int mr_noc_decode_batched(
+    const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
+    int B, int num_classes, int class_agnostic, int h, int w,
+    const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
+    double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
+    float *coords_2d, float *coords_2d_istd, float *coords_3d, float *dims, float *dims_var, float *ransac_thr, void *stream) {
+    if (B < 0 || h < 1 || w < 1 || num_classes < 1 || B > 65535) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!all_pred || !labels || !flip || !dim || !rois || !dim_means || !dim_stds || !noc_means || !noc_stds ||
+        !coords_2d || !coords_2d_istd || !coords_3d) return MR_ERR_BAD_ARGUMENT;
+    DecodeArgs a;
+    memset(&a, 0, sizeof a);
+    a.all_pred = all_pred; a.labels = (const long long *)labels; a.flip = flip; a.dim = dim; a.dim_var = dim_var; a.rois = rois;
+    a.B = B; a.C = num_classes; a.agnostic = class_agnostic; a.h = h; a.w = w;
+    a.dim_means = dim_means; a.dim_stds = dim_stds;
+    for (int k = 0; k < 3; ++k) { a.noc_mean[k] = noc_means[k]; a.noc_std[k] = noc_stds[k]; }
+    // python-scalar constants of distance_invar_proj_error_coder.py:50-54, rounded the way torch rounds them
+    const double e = ref_focal_y * epistemic_std_gain;
+    a.k_epi = (float)(e * e);
+    a.k_sd2 = (float)(proj_scaling_denominator * proj_scaling_denominator);
+    const float sdf = (float)proj_scaling_denominator;
+    a.sd_sq = sdf * sdf;
+    a.std_scale = std_scale; a.ratio = ransac_thres_ratio; a.has_var = dim_var != nullptr;
+    a.c2d = coords_2d; a.istd = coords_2d_istd; a.c3d = coords_3d; a.dims = dims; a.dims_var = dims_var;
+    a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
+    const int hw = h * w;
+    hipLaunchKernelGGL(noc_decode_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
 }
 
 // The reference's per-object entry point (ext.h:1-13).  Host fp64 buffers; one object; blocking.

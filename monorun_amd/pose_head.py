@@ -1,0 +1,162 @@
+"""Host-side mirror of the glue either side of the PnP on the hot path (forward / inference only).
+
+  * ``noc_decode``  — K2, one HIP kernel for R9-R12 + the istd / RANSAC-threshold part of R8
+    (fcn_noc_decoder.py:225-267, multiclass_norm_dim_coder.py:28-36, noc_coder.py:50-73,
+    distance_invar_proj_error_coder.py:39-60, uncert_prop_pnp_optimizer.py:73,86-88,
+    roi_align(coord_2d) at monorun_roi_head.py:521-523)
+  * ``UncertPropPnPOptimizer`` — same constructor / ``forward`` contract as
+    /root/reference/monorun/models/roi_heads/bbox_3d_heads/optimizers/uncert_prop_pnp_optimizer.py:12-99
+    (losses are training-only and out of scope: SURVEY.md §8)
+  * ``cov_correction`` — R13 (distance_invar_proj_error_coder.py:62-63 with the 'range' distance of
+    uncert_projection_head.py:104-109), applied at monorun_roi_head.py:530-534
+  * ``pose_from_head`` — the whole post-NOC-head tail in two launches (K2 -> fused PnP)
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import build_pnp
+
+# coder constants of the shipped configs (configs/kitti_multiclass.py / kitti_car.py; coder defaults)
+NOC_MEANS = (-0.1, -0.5, 0.0)
+NOC_STDS = (0.35, 0.23, 0.34)
+DIM_MEANS = ((3.89, 1.53, 1.62), (0.82, 1.78, 0.63), (1.77, 1.72, 0.57))
+DIM_STDS = ((0.44, 0.14, 0.11), (0.25, 0.13, 0.12), (0.15, 0.10, 0.14))
+
+
+def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_agnostic=False,
+               dim_means=DIM_MEANS, dim_stds=DIM_STDS, noc_means=NOC_MEANS, noc_stds=NOC_STDS,
+               ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0,
+               std_scale=10, epnp_ransac_thres_ratio=0.2):
+    """Raw NOC-head output -> PnP-boundary maps, on the device, in one kernel.
+
+    all_pred (B, 2*C*5, h, w) f32; labels (B,) int64; flip bool | (B,) bool; dim (B,3); dim_var (B,3)|None;
+    rois (B,4) xyxy or (B,5) [batch_idx, x1, y1, x2, y2] (mmdet bbox2roi).
+    Returns dict(coords_2d (B,2,h,w), coords_2d_istd (B,2,h,w), coords_3d (B,3,h,w), dims (B,3),
+                 dims_var (B,3)|None, ransac_thr (B,)|None).
+    """
+    lib = _lib.load()
+    dev = all_pred.device
+    if dev.type != 'cuda':
+        raise RuntimeError('monorun_amd.noc_decode runs on an MI355X only (no CPU fallback)')
+    B, ch, h, w = all_pred.shape
+    Cn = 1 if class_agnostic else num_classes
+    assert ch == 2 * Cn * 5, f'all_pred has {ch} channels, expected {2 * Cn * 5}'
+    f32 = dict(device=dev, dtype=torch.float32)
+    ap = all_pred.detach().to(**f32).contiguous()
+    lab = labels.detach().to(device=dev, dtype=torch.int64).contiguous()
+    if isinstance(flip, bool):
+        fl = torch.full((B,), int(flip), device=dev, dtype=torch.uint8)
+    else:
+        fl = torch.as_tensor(flip, device=dev).to(torch.uint8).contiguous()
+    dm = dim.detach().to(**f32).contiguous()
+    dv = dim_var.detach().to(**f32).contiguous() if dim_var is not None else None
+    r = rois.detach().to(**f32)
+    r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
+    t = lambda v: torch.tensor(v, **f32).contiguous()
+    mu, sd, nm, ns = t(dim_means), t(dim_stds), t(noc_means), t(noc_stds)
+    assert mu.shape == sd.shape and mu.shape[1] == 3
+    c2d = torch.empty(B, 2, h, w, **f32)
+    istd = torch.empty(B, 2, h, w, **f32)
+    c3d = torch.empty(B, 3, h, w, **f32)
+    dims = torch.empty(B, 3, **f32)
+    dims_var = torch.empty(B, 3, **f32) if dv is not None else None
+    thr = torch.empty(B, **f32) if epnp_ransac_thres_ratio is not None else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_noc_decode_batched(
+                ap.data_ptr(), lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
+                B, num_classes, int(class_agnostic), h, w, mu.data_ptr(), sd.data_ptr(), nm.data_ptr(), ns.data_ptr(),
+                float(ref_length * ref_focal_y * target_std), float(ref_focal_y), float(epistemic_std_gain), float(std_scale),
+                float(epnp_ransac_thres_ratio) if epnp_ransac_thres_ratio is not None else -1.0,
+                c2d.data_ptr(), istd.data_ptr(), c3d.data_ptr(), dims.data_ptr(),
+                dims_var.data_ptr() if dims_var is not None else None, thr.data_ptr() if thr is not None else None,
+                torch.cuda.current_stream(dev).cuda_stream))
+    return dict(coords_2d=c2d, coords_2d_istd=istd, coords_3d=c3d, dims=dims, dims_var=dims_var, ransac_thr=thr)
+
+
+def _planar_view(x):
+    """(B,C,h,w) -> (B, h*w, C) strided view; point index p = y*w + x (uncert_prop_pnp_optimizer.py:82-84)."""
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).view(b, h * w, c)
+
+
+def cov_correction(cov, t_vec, ref_length=1.6, ref_focal_y=722, target_std=0.15):
+    sd = ref_length * ref_focal_y * target_std
+    return cov * (sd / torch.norm(t_vec, p=2, dim=1)).square().view(-1, 1, 1)
+
+
+class UncertPropPnPOptimizer(nn.Module):
+    """Pose head (inference).  Constructor keywords follow the reference so that the ``pose_head`` dict
+    of the shipped configs builds unchanged; loss dicts are accepted and ignored."""
+
+    def __init__(self, loss_rot=None, loss_trans=None, loss_calib=None,
+                 rotation_coder=dict(type='Vec2DRotationCoder'),
+                 pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True,
+                          forward_exact_hessian=False),
+                 allowed_border=200, epnp_ransac_thres_ratio=0.2, std_scale=10):
+        super().__init__()
+        self.pnp = build_pnp(pnp)
+        self.epnp_ransac_thres_ratio = epnp_ransac_thres_ratio
+        self.allowed_border = allowed_border
+        self.std_scale = std_scale
+        self.cov_calib_logscale = nn.Parameter(torch.full((4, ), 0, dtype=torch.float))
+
+    def init_weights(self):
+        pass
+
+    def _ranges(self, ref, img_shapes):
+        n = img_shapes.size(0)
+        u_range = ref.new_full((n, 2), -self.allowed_border)
+        v_range = ref.new_full((n, 2), -self.allowed_border)
+        u_range[:, 1] = img_shapes[:, 1] + self.allowed_border
+        v_range[:, 1] = img_shapes[:, 0] + self.allowed_border
+        return u_range, v_range
+
+    def _calibrate(self, pose_cov):
+        s = torch.exp(self.cov_calib_logscale)
+        return (s * s[:, None]) * pose_cov
+
+    def forward(self, coords_2d, coords_2d_logstd, coords_3d, cam_intrinsic, img_shapes):
+        """
+        Args:
+            coords_2d (Tensor): shape (Nbatch, 2, h, w)
+            coords_2d_logstd (Tensor): shape (Nbatch, 2, h, w)
+            coords_3d (Tensor): shape (Nbatch, 3, h, w)
+            cam_intrinsic (Tensor): shape (Nbatch, 3, 3) or (1, 3, 3)
+            img_shapes (torch.Tensor): Shape (Nbatch, 2) or (1, 2), [H, W]
+
+        Returns:
+            ret_val (Nbatch,) bool, yaw_pred (Nbatch,1), t_vec_pred (Nbatch,3),
+            pose_cov_pred (Nbatch,4,4), pose_cov_calib (Nbatch,4,4)
+        """
+        istd = torch.exp(-coords_2d_logstd) / self.std_scale
+        u_range, v_range = self._ranges(coords_2d, img_shapes)
+        thr = None
+        if self.epnp_ransac_thres_ratio is not None:
+            thr = self.epnp_ransac_thres_ratio * (coords_2d[:, 1, -1, 0] - coords_2d[:, 1, 0, 0])
+        ret_val, yaw, t_vec, pose_cov, _ = self.pnp(_planar_view(coords_2d), _planar_view(istd), _planar_view(coords_3d),
+                                                    cam_intrinsic, u_range, v_range, thr)
+        return ret_val, yaw, t_vec, pose_cov, self._calibrate(pose_cov)
+
+    def forward_decoded(self, dec, cam_intrinsic, img_shapes):
+        """Same as ``forward`` but fed by ``noc_decode`` (istd and RANSAC threshold already on the device)."""
+        u_range, v_range = self._ranges(dec['coords_2d'], img_shapes)
+        ret_val, yaw, t_vec, pose_cov, _ = self.pnp(_planar_view(dec['coords_2d']), _planar_view(dec['coords_2d_istd']),
+                                                    _planar_view(dec['coords_3d']), cam_intrinsic, u_range, v_range,
+                                                    dec['ransac_thr'])
+        return ret_val, yaw, t_vec, pose_cov, self._calibrate(pose_cov)
+
+
+def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape,
+                   apply_cov_correction=True, **decode_kw):
+    """NOC-head output -> pose results dict (what monorun_roi_head.py:509-534 produces), two launches."""
+    dec = noc_decode(all_pred, labels, flip, dim, dim_var, rois, std_scale=pose_head.std_scale,
+                     epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, **decode_kw)
+    img_shapes = torch.as_tensor(img_shape, device=all_pred.device, dtype=torch.float32).reshape(-1, 2)
+    ret_val, yaw, t_vec, cov, cov_calib = pose_head.forward_decoded(dec, cam_intrinsic, img_shapes)
+    if apply_cov_correction:
+        kw = {k: decode_kw[k] for k in ('ref_length', 'ref_focal_y', 'target_std') if k in decode_kw}
+        cov_calib = cov_correction(cov_calib, t_vec, **kw)
+    return dict(ret_val=ret_val, yaw_pred=yaw, t_vec_pred=t_vec, pose_cov_pred=cov, pose_cov_calib=cov_calib,
+                dimensions_pred=dec['dims'], dimensions_var=dec['dims_var'])

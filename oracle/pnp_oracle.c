@@ -519,9 +519,9 @@ static void orc_one_object(const float *x2d, const float *istd, const float *x3d
                            int pn, double z_min, int inlier_opt_only, int n_hyp,
                            uint8_t *mask, uint8_t *valid, float *pose, float *cov, float *tr, float *diag) {
     int cnt = 0; for (int p = 0; p < pn; ++p) cnt += mask[p] ? 1 : 0;
-    if (!(cnt > 4)) { memset(mask, 1, (size_t)pn); }                       /* pnp_uncert_cpu.py:23-32 */
+    if (!(cnt > 4)) { for (int p = 0; p < pn; ++p) mask[p] = 1; }                       /* pnp_uncert_cpu.py:23-32 */
     double init_pose[4] = {0, 0, 0, 0}; int ok, bh = -1, bc = 0;
-    if (init) { memcpy(init_pose, init, sizeof init_pose); ok = 1; }
+    if (init) { memcpy(init_pose, init, sizeof init_pose); ok = 1; for (int p = 0; p < pn; ++p) bc += mask[p] ? 1 : 0; }
     else ok = orc_k0_init(x2d, x3d, mask, pn, K, thr != NULL, thr ? *thr : 0.0f, n_hyp, init_pose, &bh, &bc);
     double res_pose[4] = {0, 0, 0, 0}, res_tr = 0.0; int res_val = 0; double dg[6] = {0, 0, 0, 0, 0, 0};
     if (ok) {
@@ -541,7 +541,7 @@ static void orc_one_object(const float *x2d, const float *istd, const float *x3d
     for (int j = 0; j < 4; ++j) pose[j] = ok ? (float)res_pose[j] : 0.0f;
     *tr = ok ? (float)res_tr : 0.0f;
     *valid = (uint8_t)(ok && res_val);
-    if (diag) { diag[0] = (float)dg[0]; diag[1] = (float)dg[4]; diag[2] = (float)dg[1]; diag[3] = (float)bc; }
+    if (diag) { diag[0] = (float)dg[0]; diag[1] = (float)dg[4]; diag[2] = ok ? (float)dg[1] : 8.0f /* initialiser failed */; diag[3] = (float)bc; }
     /* covariance at the float32 pose, all points, final mask (pnp_uncert.py:71-85) */
     {
         double *d2 = (double *)malloc(sizeof(double) * (size_t)pn * 7); double *d3 = d2 + 2 * (size_t)pn, *dw = d3 + 3 * (size_t)pn;

@@ -1,0 +1,104 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/monorun_pnp.h declares; the Python surface mirrors monorun/ops (names, constructor, registry,
+empty batch, loud failure without a GPU).  No compute calls — there is no GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'monorun_pnp.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(?:int|void|const char \*)\s*\*?\s*([a-z_0-9]+)\s*\(', src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for n in ('mr_pnp_uncert_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_version',
+              'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count'):
+        assert n in names, names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from monorun_amd import _lib
+    assert os.path.exists(_lib.SO), 'run __graft_entry__.build() first'
+    lib = ctypes.CDLL(_lib.SO)
+    for n in _declared_functions():
+        assert hasattr(lib, n), f'{n} declared in include/monorun_pnp.h but not exported'
+    h = _lib.load()
+    assert h.mr_pnp_version() == 100
+    assert h.mr_pnp_error_string(0) == b'ok' and b'argument' in h.mr_pnp_error_string(-1)
+    for n in _lib.EXPORTED_SYMBOLS:
+        assert hasattr(h, n)
+
+
+def test_reference_signature_of_legacy_symbol():
+    """ext.h:1-13 — 5 double* in, int*, 3 double*, int, double*."""
+    from monorun_amd import _lib
+    at = _lib.load().pnp_uncert.argtypes
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert list(at) == [dp, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int), dp, dp, dp, ctypes.c_int, dp]
+
+
+def test_ops_surface_mirrors_reference():
+    import monorun_amd.ops as ops
+    assert set(ops.__all__) >= {'u2d_pnp_cpu', 'build_pnp', 'PnPUncert', 'pnp_uncert'}
+    from monorun_amd.ops import build_pnp, PnPUncert, PNP
+    m = build_pnp(dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False))
+    assert isinstance(m, PnPUncert) and isinstance(m, torch.nn.Module)
+    assert (m.z_min, m.epnp_istd_thres, m.inlier_opt_only, m.coord_istd_normalize, m.forward_exact_hessian, m.use_6dof, m.eps) == \
+           (0.5, 0.6, True, False, False, False, 1e-6)
+    assert len(list(m.state_dict())) == 0                       # no parameters or buffers, like the reference
+    d = PnPUncert()
+    assert (d.z_min, d.epnp_istd_thres, d.inlier_opt_only) == (0.5, 0.6, True)
+    with pytest.raises(TypeError):                               # the reference's latent default-dict bug is preserved:
+        build_pnp(dict(type='PnPUncert', backward_exact_hessian=True))   # pnp_uncert.py:93-99 does not accept it
+    with pytest.raises(KeyError):
+        build_pnp(dict(type='NoSuchPnP'))
+
+
+def test_empty_batch_returns_typed_empties_without_a_gpu():
+    from monorun_amd.ops import u2d_pnp_cpu
+    e = u2d_pnp_cpu(np.zeros((0, 784, 2), np.float32), np.zeros((0, 784, 2), np.float32), np.zeros((0, 784, 3), np.float32),
+                    np.eye(3, dtype=np.float32)[None], np.zeros((1, 2), np.float32), np.zeros((1, 2), np.float32))
+    assert [a.shape for a in e] == [(0,), (0, 1), (0, 3), (0, 4, 4), (0, 1), (0, 784)]
+    assert e[0].dtype == bool and e[5].dtype == bool and e[1].dtype == np.float32
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='only meaningful without a GPU')
+def test_no_cpu_fallback_fails_loudly():
+    from monorun_amd.ops import pnp_uncert, u2d_pnp_cpu
+    x = torch.zeros(2, 16, 2)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        pnp_uncert(x, x + 1, torch.zeros(2, 16, 3), torch.eye(3)[None], torch.zeros(1, 2), torch.zeros(1, 2))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        u2d_pnp_cpu(np.zeros((2, 16, 2), np.float32), np.ones((2, 16, 2), np.float32), np.zeros((2, 16, 3), np.float32),
+                    np.eye(3, dtype=np.float32)[None], np.zeros((1, 2), np.float32), np.zeros((1, 2), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    """③: only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, 'monorun_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in txt.replace('the CPU oracle', '').replace('against the CPU oracle', ''), os.path.join(dp, f)
+
+
+def test_synthetic_generator_shapes_and_determinism():
+    from monorun_amd import synthetic as syn
+    a, b = syn.make_batch(B=16, seed=1234), syn.make_batch(B=16, seed=1234)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a['coords_2d'].shape == (16, 2, 28, 28) and a['coords_3d'].shape == (16, 3, 28, 28) and a['logstd'].shape == (16, 2, 28, 28)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(a, planar=True)
+    assert x2d.strides == (1568 * 4, 4, 784 * 4) and x3d.strides == (2352 * 4, 4, 784 * 4)
+    assert np.array_equal(ur, [[-200, 1442]]) and np.array_equal(vr, [[-200, 575]])
+    np.testing.assert_allclose(thr, 0.2 * 27 / 28 * (a['rois'][:, 3] - a['rois'][:, 1]), rtol=1e-4)

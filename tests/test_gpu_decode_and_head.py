@@ -1,0 +1,129 @@
+"""GPU tests of K2 (fused NOC-head post-processing) and of the pose-head mirror against the golden
+vectors produced by the reference's coders / slice_pred / UncertPropPnPOptimizer (G3, G4)."""
+import numpy as np
+import pytest
+import torch
+
+from monorun_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def test_k2_against_reference_decode_chain(dev, g3, orc):
+    from monorun_amd.pose_head import noc_decode
+    rng = np.random.default_rng(3)
+    B = g3['all_pred'].shape[0]
+    rois = np.stack([rng.uniform(0, 900, B), rng.uniform(0, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(20, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    dec = noc_decode(t(g3['all_pred']), t(g3['labels']), t(g3['flip']), t(g3['dim']), t(g3['dim_var']), t(rois))
+    torch.cuda.synchronize()
+    c3d = dec['coords_3d'].cpu().numpy()
+    # integer channel pick + unfused fp32 mul/add chain: bit-exact against the reference's own output
+    assert np.array_equal(c3d, g3['c3d'])
+    assert np.array_equal(dec['dims'].cpu().numpy(), g3['dims']) and np.array_equal(dec['dims_var'].cpu().numpy(), g3['dims_var'])
+    # exp/log are library functions: a few ulp
+    istd_ref = np.exp(-g3['logstd_px']) / np.float32(10)
+    np.testing.assert_allclose(dec['coords_2d_istd'].cpu().numpy(), istd_ref, rtol=3e-6)
+    grid = orc.roi_grid(rois)
+    assert np.array_equal(dec['coords_2d'].cpu().numpy(), grid)
+    thr_ref = np.float32(0.2) * (grid[:, 1, -1, 0] - grid[:, 1, 0, 0])
+    assert np.array_equal(dec['ransac_thr'].cpu().numpy(), thr_ref)
+    # class-agnostic head (kitti_car.py) and no dim variance
+    dec_a = noc_decode(t(g3['all_pred'][:, :10]), t(np.zeros(B, np.int64)), t(g3['flip']), t(g3['dim']), None, t(rois),
+                       num_classes=1, class_agnostic=True)
+    noc_a = g3['noc_agnostic']
+    dims0 = g3['dim'] * np.float32([0.44, 0.14, 0.11]) + np.float32([3.89, 1.53, 1.62])
+    part = noc_a * np.float32([0.35, 0.23, 0.34])[:, None, None] + np.float32([-0.1, -0.5, 0.0])[:, None, None]
+    assert np.array_equal(dec_a['coords_3d'].cpu().numpy(), part * dims0[:, :, None, None])
+    np.testing.assert_allclose(dec_a['coords_2d_istd'].cpu().numpy(), np.exp(-g3['logstd_agnostic']) / np.float32(10), rtol=3e-6)
+    assert dec_a['dims_var'] is None
+    # bool flip for the whole batch + (B,5) mmdet rois
+    rois5 = np.concatenate([np.zeros((B, 1), np.float32), rois], 1)
+    dec_f = noc_decode(t(g3['all_pred']), t(g3['labels']), True, t(g3['dim']), t(g3['dim_var']), t(rois5))
+    noc_f, _, _ = orc.slice_pred(g3['all_pred'], g3['labels'], True)
+    d, dv = orc.dim_decode(g3['dim'], g3['dim_var'], g3['labels'])
+    assert np.array_equal(dec_f['coords_3d'].cpu().numpy(), orc.noc_decode(noc_f, d, dv)[0])
+    assert np.array_equal(dec_f['coords_2d'].cpu().numpy(), grid)
+
+
+def test_pose_head_mirror_against_reference_prep(dev, g4, orc):
+    """The tensors our head hands to the PnP equal what the reference's head handed to its PnP (G4)."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer
+    rec = {}
+
+    class Recorder(torch.nn.Module):
+        def forward(self, *a):
+            rec['a'] = a
+            n = a[0].shape[0]
+            return (torch.ones(n, dtype=torch.bool, device=a[0].device), a[0].new_zeros(n, 1), a[0].new_zeros(n, 3),
+                    torch.from_numpy(g4['pose_cov']).to(a[0].device), None)
+    head = UncertPropPnPOptimizer(
+        pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False),
+        rotation_coder=dict(type='Vec2DRotationCoder'), allowed_border=200, epnp_ransac_thres_ratio=0.2).to(dev)
+    assert list(head.state_dict()) == ['cov_calib_logscale']          # the only hot-path state in a checkpoint
+    head.pnp = Recorder()
+    with torch.no_grad():
+        head.cov_calib_logscale.copy_(torch.from_numpy(g4['cov_calib_logscale']))
+        t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+        out = head(t(g4['coords_2d']), t(g4['coords_2d_logstd']), t(g4['coords_3d']), t(g4['cam']), t(g4['img_shapes']))
+    a = rec['a']
+    assert np.array_equal(a[0].cpu().numpy(), g4['pnp_coords_2d']) and np.array_equal(a[2].cpu().numpy(), g4['pnp_coords_3d'])
+    assert [tuple(x.stride()) for x in a[:3]] == [tuple(s) for s in g4['pnp_strides']]
+    np.testing.assert_allclose(a[1].cpu().numpy(), g4['pnp_istd'], rtol=3e-6)
+    assert np.array_equal(a[4].cpu().numpy(), g4['u_range']) and np.array_equal(a[5].cpu().numpy(), g4['v_range'])
+    np.testing.assert_allclose(a[6].cpu().numpy(), g4['ransac_thr'], rtol=1e-6)
+    np.testing.assert_allclose(out[4].cpu().numpy(), g4['pose_cov_calib'], rtol=2e-6)
+
+
+def test_tail_end_to_end_two_launches(dev, orc):
+    """all_pred -> K2 -> fused PnP -> calib -> cov_correction, against the oracle fed by the numpy
+    restatement of the same chain."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
+    b = syn.make_batch(B=48, seed=99)
+    B = 48
+    rng = np.random.default_rng(5)
+    labels, flip = b['labels'], rng.uniform(size=B) < 0.5
+    C = 3
+    # invert the decode chain to synthesise a head output that decodes to the batch
+    mu, sd = orc.DIM_MEANS[labels], orc.DIM_STDS[labels]
+    dim = ((b['dims'] - mu) / sd).astype(np.float32)
+    dim_var = (rng.uniform(0.02, 0.1, (B, 3)) ** 2).astype(np.float32)
+    dims, dims_var = orc.dim_decode(dim, dim_var, labels)
+    noc = ((b['coords_3d'] / dims[:, :, None, None] - orc.NOC_MEANS[:, None, None]) / orc.NOC_STDS[:, None, None]).astype(np.float32)
+    all_pred = rng.normal(0, 1, (B, 2 * C * 5, 28, 28)).astype(np.float32)
+    _, _, chan = orc.slice_pred(all_pred, labels, flip)
+    ar = np.arange(B)
+    for k in range(3):
+        all_pred[ar, chan[:, k]] = noc[:, k]
+    for k in range(2):
+        all_pred[ar, chan[:, 3 + k]] = (b['logstd'][:, k] - np.log(2.0)).astype(np.float32) * 0.5
+    # oracle chain (numpy restatement, pinned to the reference by the G3/G4 tests)
+    n_noc, n_ls, _ = orc.slice_pred(all_pred, labels, flip)
+    c3d, c3v = orc.noc_decode(n_noc, dims, dims_var)
+    ls_px = orc.decode_logstd(n_ls, c3v)
+    c2d = orc.roi_grid(b['rois'])
+    x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(c2d, ls_px, c3d, b['img_shape'])
+    ref = orc.u2d_pnp(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
+    logscale = np.array([0.3, -0.2, 0.1, 0.5], np.float32)
+    ref_calib = orc.cov_correction(orc.cov_calib(ref[3], logscale), ref[2])
+    # product
+    head = UncertPropPnPOptimizer().to(dev)
+    with torch.no_grad():
+        head.cov_calib_logscale.copy_(torch.from_numpy(logscale))
+        t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+        res = pose_from_head(head, t(all_pred), t(labels), t(flip), t(dim), t(dim_var), t(b['rois']), t(b['K']), b['img_shape'])
+    torch.cuda.synchronize()
+    assert np.array_equal(res['ret_val'].cpu().numpy(), ref[0])
+    ok = ref[0]
+    # istd goes through exp/log (few-ulp differences) before the bit-exact-thresholded mask, so compare poses, not masks
+    assert np.abs(res['t_vec_pred'].cpu().numpy() - ref[2])[ok].max() <= 2e-3
+    dy = np.abs(np.angle(np.exp(1j * (res['yaw_pred'].cpu().numpy() - ref[1]))))[ok]
+    assert np.median(dy) <= 1e-5 and dy.max() <= 2e-3
+    rc = res['pose_cov_calib'].cpu().numpy()
+    assert np.median(np.abs(rc - ref_calib)[ok] / np.abs(ref_calib)[ok].max((1, 2), keepdims=True)) <= 1e-4

@@ -1,0 +1,268 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the fused HIP kernel, called through the C ABI,
+against the CPU oracle on identical inputs, against the committed golden vectors, and — at
+BASELINE.json's full size — through size-independent properties.
+
+Bars (north_star): integer / index / mask outputs bit-exact; pose within 1e-4 (rotation and
+translation); covariance within 1e-5 relative."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from monorun_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4
+COV_RTOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def _dv(a, dev):
+    t = torch.from_numpy(np.asarray(a))
+    d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev)
+    d.copy_(t)
+    return d
+
+
+def _run(dev, x2d, istd, x3d, K, ur, vr, thr, init=None, flags=0, z_min=0.5, thres=0.6, inlier_opt_only=True):
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    out = pnp_uncert_device(_dv(x2d, dev), _dv(istd, dev), _dv(x3d, dev), _dv(K, dev), _dv(ur, dev), _dv(vr, dev),
+                            z_min=z_min, epnp_istd_thres=thres, epnp_ransac_thres=_dv(thr, dev) if thr is not None else None,
+                            inlier_opt_only=inlier_opt_only, init_pose=_dv(init, dev) if init is not None else None,
+                            flags=flags, with_diag=True)
+    torch.cuda.synchronize()
+    valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out]
+    return valid.astype(bool), pose, cov, tr, mask.astype(bool), diag
+
+
+def _cmp(gpu, ref, tag=''):
+    valid, pose, cov, tr, mask, diag = gpu
+    r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag = ref
+    assert np.array_equal(mask, r_mask), f'{tag}: inlier mask differs in {(mask != r_mask).sum()} points'
+    assert np.array_equal(valid, r_ret), tag
+    assert np.array_equal(diag[:, 0], r_diag[:, 0]) and np.array_equal(diag[:, 2], r_diag[:, 2]), f'{tag}: LM iteration count / reason'
+    assert np.array_equal(diag[:, 3], r_diag[:, 3]), f'{tag}: K0 consensus size'
+    dyaw = np.abs(np.angle(np.exp(1j * (pose[:, 0] - r_yaw[:, 0]))))
+    assert dyaw.max() <= POSE_TOL and np.abs(pose[:, 1:] - r_t).max() <= POSE_TOL, (tag, dyaw.max(), np.abs(pose[:, 1:] - r_t).max())
+    # covariance: compared where the solve is valid (an invalid object's J^T J at the zero pose can be
+    # numerically singular, where (J^T J)^-1 is summation-order noise on both sides)
+    ok = r_ret
+    if ok.any():
+        scale = np.abs(r_cov[ok]).reshape(ok.sum(), -1).max(1)[:, None, None]
+        assert (np.abs(cov[ok] - r_cov[ok]) / scale).max() <= COV_RTOL, tag
+    ident = np.all(r_cov == np.eye(4, dtype=np.float32), axis=(1, 2))
+    assert np.array_equal(cov[ident], r_cov[ident]), tag
+    np.testing.assert_allclose(tr, r_tr[:, 0], rtol=1e-6, err_msg=tag)
+
+
+@pytest.mark.parametrize('planar', [True, False])
+@pytest.mark.parametrize('wpo', [0, 1, 2, 4, 8])
+def test_config2_batch_matches_oracle(dev, orc, planar, wpo):
+    """Seeded config-2 objects: mask/K0 bit-exact, pose 1e-4, cov 1e-5 — both layouts the pipeline
+    produces (numpy pairwise vs sequential istd mean) and every wavefronts-per-object variant."""
+    b = syn.make_batch(B=96, seed=1234)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=planar)
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+    _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, thr, flags=wpo << 8), ref, f'planar={planar} wpo={wpo}')
+
+
+def test_given_init_pose_and_no_ransac(dev, orc, batch64):
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=False)
+    init = np.concatenate([batch64['gt_yaw'][:, None], batch64['gt_t']], 1) + np.array([0.1, 0.3, -0.1, 1.0])
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, None, True, init_pose=init, return_diag=True)
+    _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, None, init=init), ref, 'given init')
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, None, False, return_diag=True)      # no RANSAC, all points in LM
+    _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, None, inlier_opt_only=False), ref, 'no ransac, all points')
+
+
+def test_per_object_cameras_and_ranges(dev, orc, batch64):
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=True)
+    n = 16
+    Kb = np.repeat(K, n, 0).copy(); Kb[:, 0, 0] *= np.linspace(0.98, 1.02, n); Kb[:, 1, 2] += np.linspace(-3, 3, n)
+    urb = np.repeat(ur, n, 0).copy(); urb[:, 0] -= np.arange(n)
+    vrb = np.repeat(vr, n, 0).copy(); vrb[:, 1] += np.arange(n)
+    ref = orc.u2d_pnp(x2d[:n], istd[:n], x3d[:n], Kb, urb, vrb, 0.5, 0.6, thr[:n], True, return_diag=True)
+    _cmp(_run(dev, x2d[:n], istd[:n], x3d[:n], Kb, urb, vrb, thr[:n]), ref, 'per-object K / ranges')
+
+
+def test_golden_covariance_from_the_reference(dev, g12):
+    """R2/R6/R7 against the reference's own jacobian.py/hessian.py/torch.inverse outputs: the kernel's
+    covariance at a GIVEN pose (LM disabled by feeding the pose as init and masking through the
+    candidate set is not possible, so use zero weights outside the inlier set and 0 LM movement)."""
+    from monorun_amd import _lib
+    B = 6
+    # make LM a no-op: evaluate at the golden pose by giving it as init with every weight intact is not a
+    # no-op, so instead check the covariance stage through its own entry: COV at the init pose with
+    # MR_COV_* needs the pose the LM returns.  We therefore compare on the LM's own output pose:
+    x2d, istd, x3d = g12['x2d'][:B].astype(np.float32), g12['istd'][:B].astype(np.float32), g12['x3d'][:B].astype(np.float32)
+    K, ur, vr = g12['K'][:B].astype(np.float32), g12['u_range'][:B].astype(np.float32), g12['v_range'][:B].astype(np.float32)
+    init = np.concatenate([g12['yaw'][:B, None], g12['t'][:B]], 1)
+    valid, pose, cov, tr, mask, diag = _run(dev, x2d, istd, x3d, K, ur, vr, None, init=init, thres=0.0, flags=_lib.MR_NO_ISTD_MASK)
+    # recompute with the reference-pinned oracle at the SAME float32 pose
+    from oracle import oracle as orc
+    for b in range(B):
+        _, _, H = orc.torch_jacobian(K[b], 0.5, ur[b], vr[b], pose[b, 0], pose[b, 1:], x2d[b], x3d[b], istd[b], mask[b])
+        ok, c = orc.pose_cov(H)
+        assert ok == valid[b]
+        assert np.abs(cov[b] - c).max() / np.abs(c).max() <= COV_RTOL, b
+
+
+def test_clamps_zclip_uclip_and_singular_object(dev, orc, g12):
+    """Objects 1 (z-clamped points), 2 (u beyond the +-200 border), 5 (skewed K), 6 (everything clamped:
+    singular J^T J -> cov = I, valid = False) from the golden fixture, solved end to end."""
+    x2d, istd, x3d = g12['x2d'].astype(np.float32), g12['istd'].astype(np.float32), g12['x3d'].astype(np.float32)
+    K, ur, vr = g12['K'].astype(np.float32), g12['u_range'].astype(np.float32), g12['v_range'].astype(np.float32)
+    init = np.concatenate([g12['yaw'][:, None], g12['t']], 1)
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, None, True, init_pose=init, return_diag=True)
+    gpu = _run(dev, x2d, istd, x3d, K, ur, vr, None, init=init)
+    _cmp(gpu, ref, 'clamp fixture')
+    assert not gpu[0][6] and np.array_equal(gpu[2][6], np.eye(4, dtype=np.float32))
+
+
+@pytest.mark.parametrize('P', [4, 5, 63, 64, 65, 100, 784, 1000])
+def test_ragged_point_counts(dev, orc, P):
+    rng = np.random.default_rng(P)
+    B = 8
+    c = syn.cube_config1(n_points=P * B, seed=P)
+    x2d = (c['pts2d'] + rng.normal(0, 0.5, c['pts2d'].shape)).reshape(B, P, 2).astype(np.float32)
+    x3d = c['pts3d'].reshape(B, P, 3).astype(np.float32)
+    istd = (np.exp(-rng.normal(np.log(2.0), 0.5, (B, P, 2))) / 10).astype(np.float32)
+    K = c['K'][None].astype(np.float32)
+    ur, vr = np.array([[-200, 1442]], np.float32), np.array([[-200, 575]], np.float32)
+    thr = np.full(B, 6.0, np.float32)
+    for planar in (False, True):
+        if planar:
+            x2d_, istd_, x3d_ = [np.ascontiguousarray(a.transpose(0, 2, 1)).transpose(0, 2, 1) for a in (x2d, istd, x3d)]
+        else:
+            x2d_, istd_, x3d_ = x2d, istd, x3d
+        ref = orc.u2d_pnp(x2d_, istd_, x3d_, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True)
+        _cmp(_run(dev, x2d_, istd_, x3d_, K, ur, vr, thr), ref, f'P={P} planar={planar}')
+
+
+def test_failure_paths_match(dev, orc, batch64):
+    x2d, istd, x3d, K, ur, vr, thr = [np.array(a) for a in syn.pnp_boundary(batch64, planar=False)]
+    n = 6
+    x2d, istd, x3d, thr = x2d[:n].copy(), istd[:n].copy(), x3d[:n].copy(), thr[:n].copy()
+    thr[0] = 1e-5                       # no hypothesis reaches 5 consensus points -> initialiser fails
+    x3d[1, :, :] = 1.0                  # degenerate geometry
+    istd[2, 4:, :] *= 1e-3              # <= 4 istd inliers -> all points, mask all-True
+    x3d[3, 7, 0] = np.nan               # NaN correspondence
+    istd[4] = 0.0                       # zero weights everywhere
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True)
+    gpu = _run(dev, x2d, istd, x3d, K, ur, vr, thr)
+    assert not ref[0][0] and not ref[0][1]
+    valid, pose, cov, tr, mask, diag = gpu
+    assert np.array_equal(valid, ref[0]) and np.array_equal(mask, ref[5])
+    assert np.array_equal(diag[:, 2], ref[6][:, 2])
+    ok = ref[0]
+    assert np.abs(pose[ok] - np.concatenate([ref[1], ref[2]], 1)[ok]).max() <= POSE_TOL
+    assert np.array_equal(pose[~ok & (diag[:, 2] == 8)], np.zeros_like(pose[~ok & (diag[:, 2] == 8)]))
+    bad = ~np.isfinite(ref[3]).all((1, 2))
+    assert np.array_equal(np.isfinite(cov).all((1, 2)), ~bad)
+    sc = np.abs(ref[3][~bad]).reshape((~bad).sum(), -1).max(1)[:, None, None]
+    assert (np.abs(cov[~bad] - ref[3][~bad]) / sc).max() <= COV_RTOL
+
+
+def test_half_and_double_inputs(dev, orc, batch64):
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=True)
+    n = 24
+    # fp64 tensors holding float32 values: identical problem
+    ref = orc.u2d_pnp(x2d[:n], istd[:n], x3d[:n], K, ur, vr, 0.5, 0.6, thr[:n], True, return_diag=True)
+    g64 = _run(dev, x2d[:n].astype(np.float64), istd[:n].astype(np.float64), x3d[:n].astype(np.float64), K, ur, vr, thr[:n],
+               flags=2)   # planar copy becomes contiguous (B,P,C) after astype -> force numpy's pairwise order of the original
+    _cmp(g64, ref, 'fp64 storage')
+    # fp16 storage (stress-config style): the oracle sees the fp16-rounded values
+    h2, hw, h3 = x2d[:n].astype(np.float16), istd[:n].astype(np.float16), x3d[:n].astype(np.float16)
+    ref16 = orc.u2d_pnp(h2.astype(np.float32), hw.astype(np.float32), h3.astype(np.float32), K, ur, vr, 0.5, 0.6, thr[:n], True, return_diag=True)
+    _cmp(_run(dev, h2, hw, h3, K, ur, vr, thr[:n], flags=1), ref16, 'fp16 storage')
+
+
+def test_legacy_per_object_c_entry_point(dev, orc, batch64):
+    """`pnp_uncert` with the reference's own signature (ext.h:1-13): host fp64 buffers, one object."""
+    from monorun_amd import _lib
+    lib = _lib.load()
+    c = syn.cube_config1()
+    dp = ctypes.POINTER(ctypes.c_double)
+    def call(p2, p3, w, K, init, clips, with_cov):
+        p2, p3, w, K, init, clips = [np.ascontiguousarray(a, np.float64) for a in (p2, p3, w, K, init, clips)]
+        val = np.zeros(1, np.int32); pose = np.zeros(4); cov = np.eye(4); tr = np.zeros(1)
+        lib.pnp_uncert(p2.ctypes.data_as(dp), p3.ctypes.data_as(dp), w.ctypes.data_as(dp), K.ctypes.data_as(dp), init.ctypes.data_as(dp),
+                       val.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), pose.ctypes.data_as(dp),
+                       cov.ctypes.data_as(dp) if with_cov else None, tr.ctypes.data_as(dp), p2.shape[0], clips.ctypes.data_as(dp))
+        return int(val[0]), pose, cov, float(tr[0])
+    val, pose, cov, tr = call(c['pts2d'], c['pts3d'], c['wgt2d'], c['K'], c['init_pose'], c['clips'], True)
+    r = orc.pnp_uncert(c['pts2d'], c['pts3d'], c['wgt2d'], c['K'], c['init_pose'], c['clips'], with_cov=True)
+    assert val == r['val'] == 1 and np.abs(pose - r['pose']).max() < 1e-9 and np.abs(pose - c['gt_pose']).max() < 1e-6
+    assert np.abs(cov - r['cov']).max() / np.abs(r['cov']).max() < 1e-8 and abs(tr - r['tr']) <= 1e-9 * r['tr']
+    # noisy object, inlier subset, no covariance requested
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=False)
+    sel = ~batch64['outlier'][2].ravel()
+    clips = np.array([0.5, -200, 1442, -200, 575.0])
+    init = np.array([batch64['gt_yaw'][2], *batch64['gt_t'][2]]) + np.array([0.1, 0.2, 0.1, 1.0])
+    val, pose, cov, tr = call(x2d[2][sel], x3d[2][sel], istd[2][sel], K[0], init, clips, False)
+    r = orc.pnp_uncert(x2d[2][sel], x3d[2][sel], istd[2][sel], K[0], init, clips)
+    assert val == r['val'] == 1 and np.abs(pose - r['pose']).max() < 1e-8 and np.array_equal(cov, np.eye(4))
+
+
+def test_torch_level_dropin_api(dev, orc, batch64):
+    """PnPUncert.forward / pnp_uncert / u2d_pnp_cpu: the reference's return contracts
+    (pnp_uncert.py:87, pnp_uncert_cpu.py:193-209) on device and host tensors."""
+    from monorun_amd.ops import build_pnp, pnp_uncert, u2d_pnp_cpu
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=True)
+    m = build_pnp(dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False))
+    t = lambda a: _dv(a, dev)
+    ret, r_vec, t_vec, cov, mask = m(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), t(thr))
+    assert ret.dtype == torch.bool and ret.shape == (64,) and r_vec.shape == (64, 1) and t_vec.shape == (64, 3)
+    assert cov.shape == (64, 4, 4) and mask.dtype == torch.bool and mask.shape == (64, 784)
+    assert all(o.device.type == 'cuda' for o in (ret, r_vec, t_vec, cov, mask)) and cov.dtype == torch.float32
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True)
+    assert np.array_equal(mask.cpu().numpy(), ref[5]) and np.abs(t_vec.cpu().numpy() - ref[2]).max() <= POSE_TOL
+    # host tensors in -> host tensors out (staged through the GPU, never solved on the CPU)
+    ret_h, r_h, t_h, cov_h, mask_h = pnp_uncert(torch.from_numpy(x2d), torch.from_numpy(istd), torch.from_numpy(x3d), torch.from_numpy(K),
+                                                torch.from_numpy(ur), torch.from_numpy(vr), 0.5, 0.6, torch.from_numpy(thr), True)
+    assert ret_h.device.type == 'cpu' and torch.equal(t_h, t_vec.cpu()) and torch.equal(mask_h, mask.cpu())
+    # numpy-level driver, with the Ceres-style covariance
+    o = u2d_pnp_cpu(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, with_pose_cov=True)
+    assert [a.shape for a in o] == [(64,), (64, 1), (64, 3), (64, 4, 4), (64, 1), (64, 784)]
+    assert o[0].dtype == bool and o[5].dtype == bool and np.array_equal(o[5], ref[5]) and np.array_equal(o[2], t_vec.cpu().numpy())
+    o2 = u2d_pnp_cpu(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, with_pose_cov=False)
+    assert o2[3] is None
+    # empty batch on the device
+    e = m(t(x2d[:0]), t(istd[:0]), t(x3d[:0]), t(K), t(ur), t(vr), t(thr[:0]))
+    assert [tuple(a.shape) for a in e] == [(0,), (0, 1), (0, 3), (0, 4, 4), (0, 784)]
+    # coord_istd_normalize pre-op (pnp_uncert.py:130-132)
+    mn = build_pnp(dict(type='PnPUncert', coord_istd_normalize=True))
+    out_n = mn(t(x2d[:8]), t(istd[:8]), t(x3d[:8]), t(K), t(ur), t(vr), t(thr[:8]))
+    assert out_n[0].all()
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 at full size (1024 x 784): size-independent properties instead of the oracle."""
+    b = syn.make_batch(B=1024, seed=1234)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    valid, pose, cov, tr, mask, diag = _run(dev, x2d, istd, x3d, K, ur, vr, thr)
+    assert valid.mean() > 0.99
+    dy = np.abs(np.angle(np.exp(1j * (pose[:, 0] - b['gt_yaw']))))
+    rel_t = np.linalg.norm(pose[:, 1:] - b['gt_t'], axis=1) / np.linalg.norm(b['gt_t'], axis=1)
+    assert np.median(dy[valid]) < 0.03 and np.median(rel_t[valid]) < 0.02
+    # covariances are symmetric positive definite
+    assert np.abs(cov - cov.transpose(0, 2, 1)).max() <= 1e-6 * np.abs(cov).max()
+    assert (np.linalg.eigvalsh(cov[valid].astype(np.float64)) > 0).all()
+    # idempotence + permutation equivariance: objects are independent, results do not depend on batch position
+    perm = np.random.default_rng(0).permutation(1024)
+    v2, p2, c2, t2, m2, d2 = _run(dev, x2d[perm], istd[perm], x3d[perm], K, ur, vr, thr[perm])
+    assert np.array_equal(p2, pose[perm]) and np.array_equal(m2, mask[perm]) and np.array_equal(c2, cov[perm])
+    # re-solving from the returned pose with the returned inlier set as the only candidates is a fixed point (<= one LM step away)
+    from monorun_amd import _lib
+    w = np.array(istd) * mask[:, :, None]
+    v3, p3, c3, t3, m3, d3 = _run(dev, x2d, w, x3d, K, ur, vr, None, init=pose.astype(np.float64), flags=_lib.MR_NO_ISTD_MASK, inlier_opt_only=False)
+    ok = valid & v3
+    assert np.abs(p3[ok] - pose[ok]).max() < 5e-2 and (d3[ok, 0] <= 3).mean() > 0.95
+    # the LM only ever lowers the cost it was given
+    assert (diag[valid, 1] >= 0).all()
