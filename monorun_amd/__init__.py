@@ -1,0 +1,10 @@
+"""monorun_amd — MI355X-native (gfx950 HIP) implementation of MonoRUn's uncertainty-aware PnP hot path.
+
+Drop-in surface: ``monorun_amd.ops`` mirrors the reference's ``monorun.ops``
+(build_pnp / PnPUncert / pnp_uncert / u2d_pnp_cpu / PNP).  See DESIGN.md and INTEGRATION.md.
+"""
+from . import _lib  # noqa: F401
+from .ops import build_pnp, PnPUncert, pnp_uncert, u2d_pnp_cpu, PNP  # noqa: F401
+from .ops.least_squares.pnp_uncert import PnPLaunch, pnp_uncert_device  # noqa: F401
+
+__version__ = '0.1.0'

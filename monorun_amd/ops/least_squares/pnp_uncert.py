@@ -65,6 +65,54 @@ def pnp_uncert_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v
     return valid, pose, cov, tr, mask, diag
 
 
+class PnPLaunch:
+    """A prepared launch of the fused kernel over device-resident inputs with preallocated outputs:
+    every ctypes argument is built once, ``run()`` only enqueues the kernel on the current stream.
+    Used where the same shapes recur (bench.py, sharded serving)."""
+
+    def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5,
+                 epnp_istd_thres=0.6, epnp_ransac_thres=None, inlier_opt_only=True, init_pose=None, flags=0,
+                 out=None, with_diag=False):
+        self.lib = _lib.load()
+        dev = coords_2d.device
+        if dev.type != 'cuda':
+            raise RuntimeError('PnPLaunch needs HIP device tensors (no CPU fallback)')
+        self.dev = dev
+        B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+        assert coords_2d.dtype in _DTYPES and coords_2d_istd.dtype == coords_2d.dtype == coords_3d.dtype
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.keep = [coords_2d, coords_2d_istd, coords_3d,
+                     cam_mats.to(**f32).reshape(-1, 3, 3).contiguous(), u_range.to(**f32).reshape(-1, 2).contiguous(),
+                     v_range.to(**f32).reshape(-1, 2).contiguous(),
+                     epnp_ransac_thres.to(**f32).reshape(-1).contiguous() if epnp_ransac_thres is not None else None,
+                     init_pose.to(device=dev, dtype=torch.float64).reshape(-1, 4).contiguous() if init_pose is not None else None]
+        x2d, istd, x3d, cam, ur, vr, thr, ini = self.keep
+        if out is None:
+            self.valid = torch.empty(B, device=dev, dtype=torch.uint8)
+            self.pose = torch.empty(B, 4, **f32)
+            self.cov = torch.empty(B, 4, 4, **f32)
+            self.tr = torch.empty(B, **f32)
+        else:                                   # e.g. the typed views of parallel.PackedResults
+            self.valid, self.pose, self.cov, self.tr = out.valid, out.pose, out.cov, out.tr
+        self.mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+        self.diag = torch.empty(B, 4, **f32) if with_diag else None
+        self.B = B
+        self.args = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d),
+                     _DTYPES[x2d.dtype], cam.data_ptr(), cam.shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                     thr.data_ptr() if thr is not None else None, ini.data_ptr() if ini is not None else None, B, P,
+                     float(z_min), float(epnp_istd_thres), int(bool(inlier_opt_only)), int(flags),
+                     self.valid.data_ptr(), self.pose.data_ptr(), self.cov.data_ptr(), self.tr.data_ptr(),
+                     self.mask.data_ptr(), self.diag.data_ptr() if self.diag is not None else None]
+
+    def run(self, stream=None):
+        if self.B == 0:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+        code = self.lib.mr_pnp_uncert_batched(*self.args, st)
+        if code:
+            _lib.check(code)
+
+
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d,
                cam_mats, u_range, v_range, z_min=0.5,
                epnp_istd_thres=1.0, epnp_ransac_thres=None,
