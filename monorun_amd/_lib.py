@@ -29,7 +29,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [SRC, os.path.join(INCLUDE, 'monorun_pnp.h')]
+    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

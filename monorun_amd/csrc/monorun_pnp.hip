@@ -1,16 +1,5 @@
-// monorun_pnp.hip — gfx950 (MI355X / CDNA4) kernels + C ABI for MonoRUn's uncertainty-aware PnP.
-//
-// One workgroup of WPO wavefronts (64 lanes each) owns one object:
-//   stage 0  coalesced load of the object's (x2d, istd, X3d) tile into an SoA image in LDS
-//   stage 1  istd inlier mask with numpy's float32 summation order          (pnp_uncert_cpu.py:164-168)
-//   stage 2  K0: deterministic consensus initialiser (replaces cv2 EPnP/RANSAC, pnp_uncert_cpu.py:35-58)
-//   stage 3  trust-region Levenberg–Marquardt, Ceres-1.14 semantics, fp64    (pnp_uncert_cpu.cpp:24-51,245-292)
-//   stage 4  pose covariance inverse(J^T J), torch masking semantics        (jacobian.py:48-98, hessian.py:67-87,
-//                                                                            pnp_uncert.py:71-85)
-// The tile stays in LDS across every LM iteration; per iteration each lane accumulates the 14 non-zero
-// scalars of {J^T J, J^T r, cost} for its points, the wave reduces them by shuffles, and every lane
-// redundantly solves the damped 4x4 system (uniform control flow, no divergence inside a workgroup).
-// No MFMA: J has 50 % structural zeros and the contraction is 4x(2P)x4 — the cost is generating J.
+// monorun_pnp.hip — gfx950 (MI355X / CDNA4) kernels + C ABI for MonoRUn's uncertainty-aware PnP hot path.
+// The C ABI is declared in include/monorun_pnp.h; the fused per-object kernel lives in pnp_kernel.inc.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -23,819 +12,42 @@
 namespace {
 
 constexpr int kMaxLeaves = 64;      // numpy pairwise-sum leaves (blocks of <=128) supported per object
+constexpr int kMaxChunks = 128;     // 64-point chunks per object (P <= 8192; LDS caps P well below that)
 constexpr int kHyp = 32;            // K0 hypotheses (the reference's RANSAC runs 30 iterations)
 constexpr uint32_t kK0Seed = 0x9E3779B9u;
 constexpr int kRedN = 24;           // doubles per wave in the cross-wave reduction scratch
 
-// numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host.
+// numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host:
+// leaves (blocks of <=128 elements) + the combine tree, internal nodes ordered by height so that the
+// kernel can evaluate it level by level.  Value slots: [0, n_leaves) leaves, n_leaves + k internal k.
 struct PairwisePlan {
-    int n_leaves, n_prog;
+    int n_leaves, n_internal, n_levels, root;
     uint16_t leaf_off[kMaxLeaves];
     uint16_t leaf_len[kMaxLeaves];
-    int8_t prog[2 * kMaxLeaves];    // postfix program: >=0 push leaf sum, -1 add the two top entries
+    uint8_t left[kMaxLeaves], right[kMaxLeaves];
+    uint8_t level_start[16];
 };
 
 struct PnpArgs {
     const void *x2d, *istd, *x3d;
-    long long s2[3], sw[3], s3[3];            // element strides (b, p, c)
+    long long s2[3], sw[3], s3[3];            // global element strides (b, p, c)
+    int contig2, contigw, contig3;             // per-object block is contiguous -> verbatim LDS-DMA copy
+    int lps2, lcs2, lpsw, lcsw, lps3, lcs3;    // LDS tile strides (point, channel) in elements
+    int tile_bytes2, tile_bytes3;              // LDS bytes of a 2-channel / 3-channel block (16-byte multiples)
+    int nca, nla;                              // LDS carve: chunk slots (multiple of 4), pairwise leaves (>= 1)
     const void *K; int K_stride; int K_f64;    // K_stride 0 (broadcast) or 9
     const void *ur, *vr; int r_stride; int r_f64;
     const float *ransac_thr;
     const double *init_pose;
-    int B, P, Ppad;
+    int B, P;
     double z_min; float istd_thres; int inlier_opt_only; int flags; int mean_mode;
     uint8_t *valid; float *pose; float *cov; float *tr; uint8_t *mask; float *diag;
     double *pose64, *cov64, *tr64;            // legacy per-object ABI outputs (nullable)
-    unsigned long long *stamps;               // debug: (B,10) s_memtime stamps + HW_ID + XCC_ID per stage (nullable)
+    unsigned long long *stamps;               // debug: (B,10) s_memtime stamps per stage + HW_ID + XCC_ID (nullable)
     PairwisePlan plan;
 };
 
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float to_f(float v) { return v; }
-__device__ __forceinline__ float to_f(__half v) { return __half2float(v); }
-__device__ __forceinline__ double to_f(double v) { return v; }
-
-template <typename T> struct Store { using type = float; };
-template <> struct Store<double> { using type = double; };
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-// Sum N doubles over the whole workgroup; every thread gets bit-identical totals.
-template <int WPO, int N>
-__device__ __forceinline__ void block_sum(double (&a)[N], double *red /* [WPO][kRedN] */) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) a[k] = wave_sum(a[k]);
-    if (WPO > 1) {
-        const int w = threadIdx.x >> 6;
-        __syncthreads();                              // previous readers of `red` are done
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) red[w * kRedN + k] = a[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            double s = red[k];
-#pragma unroll
-            for (int ww = 1; ww < WPO; ++ww) s += red[ww * kRedN + k];
-            a[k] = s;
-        }
-    }
-}
-
-// Cholesky solve of an n x n SPD system (row-major full storage), fixed operation order with explicit
-// fma so that the K0 hypotheses are reproducible against the CPU oracle.  false on a non-positive pivot.
-template <int n>
-__device__ __forceinline__ bool chol_solve(const double (&A)[n * n], const double (&b)[n], double (&x)[n]) {
-#pragma clang fp contract(off)
-    double L[n * n];
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i * n + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s = fma(-L[i * n + k], L[j * n + k], s);
-            if (i == j) {
-                if (!(s > 0.0) || !isfinite(s)) ok = false;
-                L[i * n + i] = sqrt(s);
-            } else {
-                L[i * n + j] = s / L[j * n + j];
-            }
-        }
-    }
-    double y[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-        double s = b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s = fma(-L[i * n + k], y[k], s);
-        y[i] = s / L[i * n + i];
-    }
-#pragma unroll
-    for (int i = n - 1; i >= 0; --i) {
-        double s = y[i];
-#pragma unroll
-        for (int k = i + 1; k < n; ++k) s = fma(-L[k * n + i], x[k], s);
-        x[i] = s / L[i * n + i];
-    }
-    return ok;
-}
-
-__device__ __forceinline__ bool spd_inverse4(const double (&H)[16], double (&inv)[16]) {
-    bool ok = true;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        double e[4] = {0.0, 0.0, 0.0, 0.0}, x[4];
-        e[c] = 1.0;
-        ok = chol_solve<4>(H, e, x) && ok;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) inv[4 * r + c] = x[r];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ok = ok && isfinite(inv[i]);
-    return ok;
-}
-
-// ------------------------------------------------------------------------------------ K0 pieces --
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-
-struct K4 { double fx, fy, cx, cy; };
-
-// one correspondence into the linear 4-DoF system in theta = (cos, sin, tx, ty, tz):
-//   (u-cx)(-s x + c z + tz) = fx (c x + s z + tx),  (v-cy)(-s x + c z + tz) = fy (y + ty)
-__device__ __forceinline__ void lin5_add(const K4 &k, float u, float v, float x, float y, float z,
-                                         double (&n5)[15], double (&m5)[5]) {
-#pragma clang fp contract(off)
-    const double a = (double)u - k.cx, b = (double)v - k.cy;
-    const double X = x, Y = y, Z = z;
-    const double ru[5] = { fma(a, Z, -(k.fx * X)), fma(-a, X, -(k.fx * Z)), -k.fx, 0.0, a };
-    const double rv[5] = { b * Z, -(b * X), 0.0, -k.fy, b };
-    const double rhs_v = k.fy * Y;
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-#pragma unroll
-        for (int j = i; j < 5; ++j, ++q) n5[q] = fma(rv[i], rv[j], fma(ru[i], ru[j], n5[q]));
-        m5[i] = fma(rv[i], rhs_v, m5[i]);
-    }
-}
-__device__ __forceinline__ void lin3_add(const K4 &k, double c, double s, float u, float v, float x, float y, float z,
-                                         double (&n3)[4], double (&m3)[3]) {
-#pragma clang fp contract(off)
-    const double a = (double)u - k.cx, b = (double)v - k.cy;
-    const double X = x, Y = y, Z = z;
-    const double Xr = fma(c, X, s * Z), Zr = fma(c, Z, -(s * X));
-    const double bu = fma(k.fx, Xr, -(a * Zr));
-    const double bv = fma(k.fy, Y, -(b * Zr));
-    n3[0] += 1.0; n3[1] += a; n3[2] += b; n3[3] = fma(b, b, fma(a, a, n3[3]));
-    m3[0] = fma(-k.fx, bu, m3[0]); m3[1] = fma(-k.fy, bv, m3[1]); m3[2] = fma(b, bv, fma(a, bu, m3[2]));
-}
-__device__ __forceinline__ bool lin5_solve(const double (&n5)[15], const double (&m5)[5], double &c, double &s) {
-#pragma clang fp contract(off)
-    double A[25], th[5];
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = i; j < 5; ++j, ++q) { A[5 * i + j] = n5[q]; A[5 * j + i] = n5[q]; }
-    bool ok = chol_solve<5>(A, m5, th);
-    const double rho2 = fma(th[0], th[0], th[1] * th[1]);
-    ok = ok && (rho2 > 1e-12) && isfinite(rho2);
-    const double inv = 1.0 / sqrt(rho2);
-    c = th[0] * inv; s = th[1] * inv;
-    return ok;
-}
-__device__ __forceinline__ bool lin3_solve(const K4 &k, const double (&n3)[4], const double (&m3)[3], double (&t)[3]) {
-#pragma clang fp contract(off)
-    const double A[9] = { k.fx * k.fx * n3[0], 0.0, -k.fx * n3[1],
-                          0.0, k.fy * k.fy * n3[0], -k.fy * n3[2],
-                          -k.fx * n3[1], -k.fy * n3[2], n3[3] };
-    bool ok = chol_solve<3>(A, m3, t);
-    return ok && isfinite(t[0]) && isfinite(t[1]) && isfinite(t[2]);
-}
-__device__ __forceinline__ bool consensus(float c, float s, float tx, float ty, float tz, float fx, float fy,
-                                          float a, float b, float x, float y, float z, float thr) {
-#pragma clang fp contract(off)
-    const float Xc = fmaf(c, x, fmaf(s, z, tx));
-    const float Zc = fmaf(c, z, fmaf(-s, x, tz));
-    const float Yc = y + ty;
-    const float eu = fmaf(-a, Zc, fx * Xc);
-    const float ev = fmaf(-b, Zc, fy * Yc);
-    const float e2 = fmaf(eu, eu, ev * ev);
-    const float lim = thr * Zc;
-    return (Zc > 0.0f) && (e2 <= lim * lim);
-}
-
-// ------------------------------------------------------------------------------------ LM pieces --
-struct Cam { double fx, fy, cx, cy, zmin, umin, umax, vmin, vmax; };
-
-// accumulator slots: 0..8 = H00 H01 H02 H03 H11 H13 H22 H23 H33 (H12 == 0 structurally), 9..12 = g, 13 = sum r^2
-constexpr int kAcc = 14;
-
-// Residual + Jacobian of one correspondence with the semantics of Ceres autodiff on
-// ReprojectionErrorArray (pnp_uncert_cpu.cpp:24-51): a clamped quantity becomes a constant, so the
-// z-clamp removes only dZ, and a u/v clamp removes that whole row.
-__device__ __forceinline__ void eval_point(const Cam &k, double c, double s, double tx, double ty, double tz,
-                                           double u, double v, double wu, double wv, double x, double y, double z,
-                                           double (&acc)[kAcc]) {
-    const double Bv = c * x + s * z;               // Xc - tx ;  dZc/dyaw = -Bv
-    const double A = c * z - s * x;                // Zc - tz ;  dXc/dyaw =  A
-    const double Xc = Bv + tx, Yc = y + ty, Zc = A + tz;
-    const bool zc = Zc < k.zmin;
-    const double Zu = zc ? k.zmin : Zc;
-    const double iz = 1.0 / Zu;
-    const double px = k.fx * Xc * iz, py = k.fy * Yc * iz;
-    double pu = px + k.cx, pv = py + k.cy;
-    const bool ucl = (pu < k.umin) || (pu > k.umax);
-    const bool vcl = (pv < k.vmin) || (pv > k.vmax);
-    pu = (pu < k.umin) ? k.umin : ((pu > k.umax) ? k.umax : pu);
-    pv = (pv < k.vmin) ? k.vmin : ((pv > k.vmax) ? k.vmax : pv);
-    const double ru = wu * (pu - u), rv = wv * (pv - v);
-    const double dZy = zc ? 0.0 : -Bv, dZt = zc ? 0.0 : 1.0;
-    const double wuz = ucl ? 0.0 : wu * iz, wvz = vcl ? 0.0 : wv * iz;
-    const double ju0 = wuz * (k.fx * A - px * dZy);
-    const double ju1 = wuz * k.fx;
-    const double ju3 = -wuz * px * dZt;
-    const double jv0 = -wvz * py * dZy;
-    const double jv2 = wvz * k.fy;
-    const double jv3 = -wvz * py * dZt;
-    acc[0] += ju0 * ju0 + jv0 * jv0;
-    acc[1] += ju0 * ju1;
-    acc[2] += jv0 * jv2;
-    acc[3] += ju0 * ju3 + jv0 * jv3;
-    acc[4] += ju1 * ju1;
-    acc[5] += ju1 * ju3;
-    acc[6] += jv2 * jv2;
-    acc[7] += jv2 * jv3;
-    acc[8] += ju3 * ju3 + jv3 * jv3;
-    acc[9] += ju0 * ru + jv0 * rv;
-    acc[10] += ju1 * ru;
-    acc[11] += jv2 * rv;
-    acc[12] += ju3 * ru + jv3 * rv;
-    acc[13] += ru * ru + rv * rv;
-}
-
-struct Eval { double cost; double g[4]; double H[16]; bool ok; };
-
-template <int WPO, typename S>
-__device__ __forceinline__ void evaluate(const Cam &k, const double (&x)[4], int P, int Ppad, bool use_mask,
-                                         const S *su, const S *sv, const S *swu, const S *swv,
-                                         const S *sx, const S *sy, const S *sz, const uint8_t *smask,
-                                         double *red, Eval &e) {
-    constexpr int NT = 64 * WPO;
-    double sn, cs;
-    sincos(x[0], &sn, &cs);
-    double acc[kAcc];
-#pragma unroll
-    for (int i = 0; i < kAcc; ++i) acc[i] = 0.0;
-#pragma unroll 2
-    for (int p = threadIdx.x; p < Ppad; p += NT) {
-        // points outside the inlier set are not part of the problem at all (pnp_uncert_cpu.py:62-66):
-        // skip them instead of zero-weighting them so that a NaN correspondence there cannot poison the sums
-        if (use_mask ? (smask[p] != 0) : (p < P))
-            eval_point(k, cs, sn, x[1], x[2], x[3], (double)su[p], (double)sv[p], (double)swu[p], (double)swv[p],
-                       (double)sx[p], (double)sy[p], (double)sz[p], acc);
-    }
-    block_sum<WPO, kAcc>(acc, red);
-    e.cost = 0.5 * acc[13];
-    e.g[0] = acc[9]; e.g[1] = acc[10]; e.g[2] = acc[11]; e.g[3] = acc[12];
-    e.H[0] = acc[0]; e.H[1] = acc[1]; e.H[2] = acc[2]; e.H[3] = acc[3];
-    e.H[4] = acc[1]; e.H[5] = acc[4]; e.H[6] = 0.0;    e.H[7] = acc[5];
-    e.H[8] = acc[2]; e.H[9] = 0.0;    e.H[10] = acc[6]; e.H[11] = acc[7];
-    e.H[12] = acc[3]; e.H[13] = acc[5]; e.H[14] = acc[7]; e.H[15] = acc[8];
-    bool ok = isfinite(e.cost);
-#pragma unroll
-    for (int i = 0; i < 13; ++i) ok = ok && isfinite(acc[i]);
-    e.ok = ok;
-}
-
-enum { WHY_GRADIENT = 1, WHY_PARAMETER = 2, WHY_FUNCTION = 3, WHY_MAXITER = 4, WHY_MINRADIUS = 5,
-       WHY_INVALID = 6, WHY_EVALFAIL = 7, WHY_K0FAIL = 8 };
-
-struct LmResult { double x[4]; double radius; double cost; int iters; int why; bool usable; };
-
-// Ceres 1.14 TrustRegionMinimizer + LevenbergMarquardtStrategy with default options (only
-// linear_solver_type = DENSE_QR is set by the reference, pnp_uncert_cpu.cpp:270-271); the QR solve of
-// [J; D] y = [r; 0] is done through its (Jacobi-scaled, 4x4, fp64) normal equations.
-template <int WPO, typename S>
-__device__ void lm_solve(const Cam &k, const double (&init)[4], int P, int Ppad, bool use_mask,
-                         const S *su, const S *sv, const S *swu, const S *swv,
-                         const S *sx, const S *sy, const S *sz, const uint8_t *smask,
-                         double *red, LmResult &r) {
-    const int max_num_iterations = 50;
-    const double max_radius = 1e16, min_radius = 1e-32;
-    const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
-    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-
-    double x[4] = { init[0], init[1], init[2], init[3] };
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.x[j] = x[j];
-    double radius = 1e4, decrease_factor = 2.0;
-    r.iters = 0; r.why = 0; r.usable = false; r.radius = radius; r.cost = 0.0;
-
-    Eval cur;
-    evaluate<WPO, S>(k, x, P, Ppad, use_mask, su, sv, swu, swv, sx, sy, sz, smask, red, cur);
-    if (!cur.ok) { r.why = WHY_EVALFAIL; r.radius = 0.0; return; }
-    double scale[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) scale[j] = 1.0 / (1.0 + sqrt(cur.H[5 * j]));
-    double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-    bool last_successful = true;
-    int iteration = 0, invalid_run = 0;
-
-    for (;;) {
-        // FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (last_successful) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r.x[j] = x[j];
-            r.cost = cur.cost;
-        }
-        r.radius = radius; r.iters = iteration;
-        if (iteration >= max_num_iterations) { r.why = WHY_MAXITER; r.usable = true; return; }
-        if (last_successful) {
-            double gmax = fmax(fmax(fabs(cur.g[0]), fabs(cur.g[1])), fmax(fabs(cur.g[2]), fabs(cur.g[3])));
-            if (gmax <= gradient_tolerance) { r.why = WHY_GRADIENT; r.usable = true; return; }
-        }
-        if (radius <= min_radius) { r.why = WHY_MINRADIUS; r.usable = true; return; }
-
-        ++iteration; last_successful = false;
-        // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian
-        double Hs[16], gs[4], A[16], y[4], step[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            gs[a] = cur.g[a] * scale[a];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) Hs[4 * a + b] = cur.H[4 * a + b] * scale[a] * scale[b];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) A[i] = Hs[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double d = fmin(fmax(Hs[5 * j], min_lm_diagonal), max_lm_diagonal);
-            A[5 * j] += d / radius;
-        }
-        bool step_ok = chol_solve<4>(A, gs, y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { step[j] = -y[j]; step_ok = step_ok && isfinite(step[j]); }
-        double model_cost_change = 0.0;
-        if (step_ok) {
-            double sg = 0.0, sHs = 0.0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                sg += step[a] * gs[a];
-                double t = 0.0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) t += Hs[4 * a + b] * step[b];
-                sHs += step[a] * t;
-            }
-            model_cost_change = -(sg + 0.5 * sHs);
-            step_ok = model_cost_change > 0.0;
-        }
-        if (!step_ok) {                                   // HandleInvalidStep
-            if (++invalid_run >= 5) { r.why = WHY_INVALID; r.usable = false; r.iters = iteration; return; }
-            radius *= 0.5;
-            continue;
-        }
-        invalid_run = 0;
-        double cand[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cand[j] = x[j] + step[j] * scale[j];
-        Eval nxt;                                         // cost, and speculatively g/H, at the candidate
-        evaluate<WPO, S>(k, cand, P, Ppad, use_mask, su, sv, swu, swv, sx, sy, sz, smask, red, nxt);
-        const double cand_cost = nxt.ok ? nxt.cost : 1.7976931348623157e308;
-        double step_norm = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const double d = x[j] - cand[j]; step_norm += d * d; }
-        step_norm = sqrt(step_norm);
-        if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) {
-            r.why = WHY_PARAMETER; r.usable = true; r.iters = iteration; return; }
-        const double cost_change = cur.cost - cand_cost;
-        if (fabs(cost_change) <= function_tolerance * cur.cost) {
-            r.why = WHY_FUNCTION; r.usable = true; r.iters = iteration; return; }
-        const double relative_decrease = cost_change / model_cost_change;
-        if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep + StepAccepted
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = cand[j];
-            x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-            cur = nxt;
-            last_successful = true;
-            const double t = 2.0 * relative_decrease - 1.0;
-            radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-            radius = fmin(max_radius, radius);
-            decrease_factor = 2.0;
-        } else {                                          // StepRejected
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-template <typename T, typename S>
-__device__ __forceinline__ void load_tile(const T *src, long long sb, long long sp, long long sc, int C, int b, int P,
-                                          int Ppad, int NT, S *dst /* [C][Ppad] */, S pad_last) {
-    const T *base = src + (long long)b * sb;
-    if (sc == 1 && sp == C) {
-        // contiguous (P, C) block: flat coalesced sweep, de-interleaved into the SoA image
-        const int n = P * C;
-        for (int e = threadIdx.x; e < n; e += NT) {
-            const int p = e / C, c = e - p * C;
-            dst[c * Ppad + p] = (S)to_f(base[e]);
-        }
-    } else {
-        // channel-planar (sp == 1: lane-consecutive points are address-consecutive) or any other strides
-        for (int c = 0; c < C; ++c) {
-            const T *bc = base + (long long)c * sc;
-            for (int p = threadIdx.x; p < P; p += NT) dst[c * Ppad + p] = (S)to_f(bc[(long long)p * sp]);
-        }
-    }
-    for (int c = 0; c < C; ++c)
-        for (int p = P + threadIdx.x; p < Ppad; p += NT) dst[c * Ppad + p] = (c == C - 1) ? pad_last : (S)0;
-}
-
-__device__ __forceinline__ double ld_k(const void *p, int f64, long long i) {
-    return f64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
-}
-
-template <typename T, int WPO>
-__global__ void __launch_bounds__(64 * WPO) pnp_uncert_kernel(const PnpArgs a) {
-    using S = typename Store<T>::type;
-    constexpr int NT = 64 * WPO;
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int P = a.P, Ppad = a.Ppad;
-
-    extern __shared__ __align__(16) unsigned char smem[];
-#define MR_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(long long)b * 10 + (i)] = __builtin_readcyclecounter(); } while (0)
-    MR_STAMP(0);
-    if (a.stamps && tid == 0) { a.stamps[(long long)b * 10 + 8] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); a.stamps[(long long)b * 10 + 9] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
-    double *red = (double *)smem;                                   // [WPO][kRedN]
-    unsigned long long *sball = (unsigned long long *)(red + WPO * kRedN);   // [Ppad/64]
-    S *su = (S *)(sball + ((Ppad / 64 + 1) & ~1));                  // keep the tile 16-byte aligned
-    S *sv = su + Ppad, *swu = sv + Ppad, *swv = swu + Ppad, *sx = swv + Ppad, *sy = sx + Ppad, *sz = sy + Ppad;
-    float *shyp = (float *)(sz + Ppad);                             // [kHyp][8]
-    int *scnt = (int *)(shyp + kHyp * 8);                           // [WPO][kHyp]
-    float *spw = (float *)(scnt + WPO * kHyp);                      // [2][kMaxLeaves*8] pairwise partials
-    float *sleaf = spw + 2 * kMaxLeaves * 8;                        // [2][kMaxLeaves]
-    float *sstk = sleaf + 2 * kMaxLeaves;                           // [2][16] + [2] results
-    uint16_t *slist = (uint16_t *)(sstk + 2 * 16 + 2);              // [Ppad]
-    uint8_t *smask = (uint8_t *)(slist + Ppad);                     // [Ppad]
-
-    // ---------------------------------------------------------------- stage 0: tile -> LDS (SoA)
-    load_tile<T, S>((const T *)a.x2d, a.s2[0], a.s2[1], a.s2[2], 2, b, P, Ppad, NT, su, (S)0);
-    load_tile<T, S>((const T *)a.istd, a.sw[0], a.sw[1], a.sw[2], 2, b, P, Ppad, NT, swu, (S)0);
-    load_tile<T, S>((const T *)a.x3d, a.s3[0], a.s3[1], a.s3[2], 3, b, P, Ppad, NT, sx, (S)1);   // padded points: z = 1, w = 0
-    const long long ko = (long long)b * a.K_stride, ro = (long long)b * a.r_stride;
-    double Kd[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Kd[i] = ld_k(a.K, a.K_f64, ko + i);
-    Cam cam;
-    cam.fx = Kd[0]; cam.fy = Kd[4]; cam.cx = Kd[2]; cam.cy = Kd[5];      // pnp_uncert_cpu.cpp:265
-    cam.zmin = a.z_min;
-    cam.umin = ld_k(a.ur, a.r_f64, ro); cam.umax = ld_k(a.ur, a.r_f64, ro + 1);
-    cam.vmin = ld_k(a.vr, a.r_f64, ro); cam.vmax = ld_k(a.vr, a.r_f64, ro + 1);
-    __syncthreads();
-
-    MR_STAMP(1);
-    // ---------------------------------------------------------------- stage 1: istd inlier mask (R4)
-    if (a.flags & MR_NO_ISTD_MASK) {
-        for (int p = tid; p < Ppad; p += NT) smask[p] = (p < P) ? 1 : 0;
-        __syncthreads();
-    } else {
-        float *sres = sstk + 32;
-        if (a.mean_mode == MR_MEAN_SEQUENTIAL) {
-            // numpy reduces a C-contiguous (B,P,2) float32 array over axis 1 strictly in p order
-            if (tid < 2) {
-                const S *w = tid ? swv : swu;
-                float s = 0.0f;
-                for (int p = 0; p < P; ++p) s += (float)w[p];
-                sres[tid] = s;
-            }
-        } else {
-            // numpy pairwise summation (point axis contiguous): 8 strided accumulators per <=128 block
-            const int nl = a.plan.n_leaves;
-            for (int t = tid; t < 2 * nl * 8; t += NT) {
-                const int c = t / (nl * 8), rem = t - c * nl * 8, leaf = rem >> 3, j = rem & 7;
-                const S *w = (c ? swv : swu) + a.plan.leaf_off[leaf];
-                const int len = a.plan.leaf_len[leaf];
-                float acc = 0.0f;
-                if (len < 8) {
-                    if (j == 0) for (int i = 0; i < len; ++i) acc += (float)w[i];
-                } else {
-                    acc = (float)w[j];
-                    for (int i = 8; i < len - (len & 7); i += 8) acc += (float)w[i + j];
-                }
-                spw[t] = acc;
-            }
-            __syncthreads();
-            for (int t = tid; t < 2 * nl; t += NT) {
-                const int c = t / nl, leaf = t - c * nl;
-                const float *r8 = spw + (c * nl + leaf) * 8;
-                const int len = a.plan.leaf_len[leaf];
-                float res;
-                if (len < 8) res = r8[0];
-                else {
-                    res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-                    const S *w = (c ? swv : swu) + a.plan.leaf_off[leaf];
-                    for (int i = len - (len & 7); i < len; ++i) res += (float)w[i];
-                }
-                sleaf[c * kMaxLeaves + leaf] = res;
-            }
-            __syncthreads();
-            if (tid < 2) {
-                float *stk = sstk + tid * 16;
-                int sp = 0;
-                for (int i = 0; i < a.plan.n_prog; ++i) {
-                    const int op = a.plan.prog[i];
-                    if (op >= 0) stk[sp++] = sleaf[tid * kMaxLeaves + op];
-                    else { const float r = stk[sp - 2] + stk[sp - 1]; sp -= 2; stk[sp++] = r; }
-                }
-                sres[tid] = stk[0];
-            }
-        }
-        __syncthreads();
-        // mean = sum / P ; threshold = float32(thres) * mean ; both axes must pass (pnp_uncert_cpu.py:164-168)
-        const float thr_u = a.istd_thres * (sres[0] / (float)P);
-        const float thr_v = a.istd_thres * (sres[1] / (float)P);
-        int cnt = 0;
-        for (int p = tid; p < Ppad; p += NT) {
-            const bool in = (p < P) && ((float)swu[p] >= thr_u) && ((float)swv[p] >= thr_v);
-            smask[p] = in ? 1 : 0;
-            cnt += in ? 1 : 0;
-        }
-        double c1[1] = { (double)cnt };
-        block_sum<WPO, 1>(c1, red);
-        if (!(c1[0] > 4.0)) {                                       // pnp_uncert_cpu.py:23-32
-            for (int p = tid; p < Ppad; p += NT) smask[p] = (p < P) ? 1 : 0;
-        }
-        __syncthreads();
-    }
-
-    MR_STAMP(2);
-    // ---------------------------------------------------------------- stage 2: K0 initialiser (R5)
-    double init[4] = { 0.0, 0.0, 0.0, 0.0 };
-    bool init_ok = true;
-    float k0_count = 0.0f;
-    if (a.init_pose) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) init[j] = a.init_pose[(long long)b * 4 + j];
-        int cnt = 0;
-        for (int p = tid; p < Ppad; p += NT) cnt += smask[p];
-        double c1[1] = { (double)cnt };
-        block_sum<WPO, 1>(c1, red);
-        k0_count = (float)c1[0];
-    } else {
-        const K4 k4 = { cam.fx, cam.fy, cam.cx, cam.cy };
-        const float fxf = (float)cam.fx, fyf = (float)cam.fy, cxf = (float)cam.cx, cyf = (float)cam.cy;
-        // ordered compaction of the candidate indices
-        for (int p = tid; p < Ppad; p += NT) {
-            const unsigned long long bal = __ballot(smask[p] != 0);
-            if (lane == 0) sball[p >> 6] = bal;
-        }
-        __syncthreads();
-        int n = 0;
-        for (int p = tid; p < Ppad; p += NT) {
-            const int chunk = p >> 6;
-            int base = 0;
-            for (int q = 0; q < chunk; ++q) base += __popcll(sball[q]);
-            const unsigned long long bal = sball[chunk];
-            if ((bal >> lane) & 1ull) slist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)p;
-        }
-        for (int q = 0; q < Ppad / 64; ++q) n += __popcll(sball[q]);
-        __syncthreads();
-        k0_count = (float)n;
-        const bool use_ransac = a.ransac_thr != nullptr;
-        if (use_ransac) {
-            const float thr = a.ransac_thr[b];
-            // hypotheses: lane h of wave 0 solves hypothesis h from 5 stratified samples (fp64, serial)
-            if (tid < kHyp) {
-                bool ok = n >= 5;
-                double c = 0.0, s = 0.0, t[3] = { 0.0, 0.0, 0.0 };
-                if (ok) {
-                    double n5[15], m5[5], n3[4] = { 0, 0, 0, 0 }, m3[3] = { 0, 0, 0 };
-                    int idx[5];
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) n5[i] = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) m5[i] = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const uint32_t lo = (uint32_t)(((uint64_t)j * (uint64_t)n) / 5u), hi = (uint32_t)(((uint64_t)(j + 1) * (uint64_t)n) / 5u);
-                        const uint32_t rr = lo + (uint32_t)(((uint64_t)hash32(kK0Seed + (uint32_t)tid * 8u + (uint32_t)j) * (uint64_t)(hi - lo)) >> 32);
-                        idx[j] = slist[rr];
-                        const int p = idx[j];
-                        lin5_add(k4, (float)su[p], (float)sv[p], (float)sx[p], (float)sy[p], (float)sz[p], n5, m5);
-                    }
-                    ok = lin5_solve(n5, m5, c, s);
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const int p = idx[j];
-                        lin3_add(k4, c, s, (float)su[p], (float)sv[p], (float)sx[p], (float)sy[p], (float)sz[p], n3, m3);
-                    }
-                    ok = lin3_solve(k4, n3, m3, t) && ok;
-                }
-                const float nanf_ = __int_as_float(0x7fc00000);
-                shyp[tid * 8 + 0] = ok ? (float)c : nanf_;
-                shyp[tid * 8 + 1] = ok ? (float)s : nanf_;
-                shyp[tid * 8 + 2] = ok ? (float)t[0] : nanf_;
-                shyp[tid * 8 + 3] = ok ? (float)t[1] : nanf_;
-                shyp[tid * 8 + 4] = ok ? (float)t[2] : nanf_;
-            }
-            __syncthreads();
-            MR_STAMP(3);
-            // consensus of every hypothesis over the candidates (fp32, fixed operation order)
-            int cnt[kHyp];
-#pragma unroll
-            for (int h = 0; h < kHyp; ++h) cnt[h] = 0;
-            for (int p = tid; p < Ppad; p += NT) {
-                const float pa = (float)su[p] - cxf, pb = (float)sv[p] - cyf;
-                const float px = (float)sx[p], py = (float)sy[p], pz = (float)sz[p];
-                const bool m = smask[p] != 0;
-#pragma unroll
-                for (int h = 0; h < kHyp; ++h) {
-                    const float4 hp = *(const float4 *)(shyp + h * 8);
-                    const float htz = shyp[h * 8 + 4];
-                    const bool in = m && consensus(hp.x, hp.y, hp.z, hp.w, htz, fxf, fyf, pa, pb, px, py, pz, thr);
-                    cnt[h] += __popcll(__ballot(in));
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int h = 0; h < kHyp; ++h) scnt[wid * kHyp + h] = cnt[h];
-            }
-            __syncthreads();
-            int best = -1, bestc = 0;
-            for (int h = 0; h < kHyp; ++h) {
-                int ch = 0;
-                for (int w = 0; w < WPO; ++w) ch += scnt[w * kHyp + h];
-                if (ch > bestc) { bestc = ch; best = h; }
-            }
-            k0_count = (float)bestc;
-            if (best < 0 || bestc < 5) init_ok = false;
-            else {
-                const float4 hp = *(const float4 *)(shyp + best * 8);
-                const float htz = shyp[best * 8 + 4];
-                for (int p = tid; p < Ppad; p += NT) {
-                    const bool in = (smask[p] != 0) &&
-                        consensus(hp.x, hp.y, hp.z, hp.w, htz, fxf, fyf, (float)su[p] - cxf, (float)sv[p] - cyf,
-                                  (float)sx[p], (float)sy[p], (float)sz[p], thr);
-                    smask[p] = in ? 1 : 0;
-                }
-            }
-            __syncthreads();
-        }
-        MR_STAMP(4);
-        if (init_ok) {
-            // refit on the final set with the same linear solver (fp64 accumulation, tree reduction)
-            double acc20[20];
-#pragma unroll
-            for (int i = 0; i < 20; ++i) acc20[i] = 0.0;
-            {
-                double n5[15], m5[5];
-#pragma unroll
-                for (int i = 0; i < 15; ++i) n5[i] = 0.0;
-#pragma unroll
-                for (int i = 0; i < 5; ++i) m5[i] = 0.0;
-                for (int p = tid; p < Ppad; p += NT)
-                    if (smask[p]) lin5_add(k4, (float)su[p], (float)sv[p], (float)sx[p], (float)sy[p], (float)sz[p], n5, m5);
-#pragma unroll
-                for (int i = 0; i < 15; ++i) acc20[i] = n5[i];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) acc20[15 + i] = m5[i];
-            }
-            block_sum<WPO, 20>(acc20, red);
-            double n5[15], m5[5], c, s;
-#pragma unroll
-            for (int i = 0; i < 15; ++i) n5[i] = acc20[i];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) m5[i] = acc20[15 + i];
-            init_ok = lin5_solve(n5, m5, c, s);
-            double acc7[7] = { 0, 0, 0, 0, 0, 0, 0 };
-            {
-                double n3[4] = { 0, 0, 0, 0 }, m3[3] = { 0, 0, 0 };
-                for (int p = tid; p < Ppad; p += NT)
-                    if (smask[p]) lin3_add(k4, c, s, (float)su[p], (float)sv[p], (float)sx[p], (float)sy[p], (float)sz[p], n3, m3);
-                acc7[0] = n3[0]; acc7[1] = n3[1]; acc7[2] = n3[2]; acc7[3] = n3[3];
-                acc7[4] = m3[0]; acc7[5] = m3[1]; acc7[6] = m3[2];
-            }
-            block_sum<WPO, 7>(acc7, red);
-            const double n3[4] = { acc7[0], acc7[1], acc7[2], acc7[3] }, m3[3] = { acc7[4], acc7[5], acc7[6] };
-            double t[3];
-            init_ok = lin3_solve(k4, n3, m3, t) && init_ok;
-            init[0] = atan2(s, c); init[1] = t[0]; init[2] = t[1]; init[3] = t[2];
-        }
-    }
-
-    MR_STAMP(5);
-    // ---------------------------------------------------------------- stage 3: LM refinement (R1,R3)
-    LmResult lm;
-    lm.x[0] = lm.x[1] = lm.x[2] = lm.x[3] = 0.0; lm.radius = 0.0; lm.cost = 0.0; lm.iters = 0; lm.why = WHY_K0FAIL; lm.usable = false;
-    if (init_ok)
-        lm_solve<WPO, S>(cam, init, P, Ppad, a.inlier_opt_only != 0, su, sv, swu, swv, sx, sy, sz, smask, red, lm);
-    const bool pose_ok = init_ok;
-    float posef[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) posef[j] = pose_ok ? (float)lm.x[j] : 0.0f;       // pnp_uncert_cpu.py:108-125
-    bool valid = pose_ok && lm.usable;
-
-    MR_STAMP(6);
-    // ---------------------------------------------------------------- stage 4: covariance (R2,R6,R7)
-    double cov[16];
-    bool have_cov = false;
-    if (!(a.flags & MR_COV_NONE)) {
-        have_cov = true;
-        double H[16];
-        if (a.flags & MR_COV_CERES) {
-            Eval e;
-            double xe[4] = { lm.x[0], lm.x[1], lm.x[2], lm.x[3] };
-            evaluate<WPO, S>(cam, xe, P, Ppad, a.inlier_opt_only != 0, su, sv, swu, swv, sx, sy, sz, smask, red, e);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) H[i] = e.H[i];
-        } else {
-            // torch semantics at the float32 pose, all points, masked by the final inlier set:
-            // zero_mask = z_clip | uv_clip(axis) | outlier ; full upper 2x3 of K (jacobian.py:20-26,52-95)
-            const double yaw = (double)posef[0], tx = (double)posef[1], ty = (double)posef[2], tz = (double)posef[3];
-            double sn, cs;
-            sincos(yaw, &sn, &cs);
-            double kr[9], kt[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                kr[3 * r + 0] = Kd[3 * r + 0] * cs - Kd[3 * r + 2] * sn;
-                kr[3 * r + 1] = Kd[3 * r + 1];
-                kr[3 * r + 2] = Kd[3 * r + 0] * sn + Kd[3 * r + 2] * cs;
-                kt[r] = Kd[3 * r + 0] * tx + Kd[3 * r + 1] * ty + Kd[3 * r + 2] * tz;
-            }
-            const double m1[4] = { Kd[0] * (-sn) + Kd[2] * (-cs), Kd[0] * cs + Kd[2] * (-sn),
-                                   Kd[3] * (-sn) + Kd[5] * (-cs), Kd[3] * cs + Kd[5] * (-sn) };
-            double hacc[10];
-#pragma unroll
-            for (int i = 0; i < 10; ++i) hacc[i] = 0.0;
-            for (int p = tid; p < Ppad; p += NT) {
-                const double X = (double)sx[p], Y = (double)sy[p], Z = (double)sz[p];
-                const double un = kr[0] * X + kr[1] * Y + kr[2] * Z + kt[0];
-                const double vn = kr[3] * X + kr[4] * Y + kr[5] * Z + kt[1];
-                double z = kr[6] * X + kr[7] * Y + kr[8] * Z + kt[2];
-                const bool zclip = z < cam.zmin;
-                z = zclip ? cam.zmin : z;
-                const double iz = 1.0 / z;
-                double uv[2] = { un * iz, vn * iz };
-                const bool cl[2] = { (uv[0] < cam.umin) || (uv[0] > cam.umax), (uv[1] < cam.vmin) || (uv[1] > cam.vmax) };
-                uv[0] = fmax(cam.umin, fmin(cam.umax, uv[0]));
-                uv[1] = fmax(cam.vmin, fmin(cam.vmax, uv[1]));
-                const bool outl = smask[p] == 0;
-                double J[8];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    // jac[zero_mask] = 0 is an assignment (jacobian.py:70,95): select, do not multiply by zero
-                    const bool zero = zclip || cl[r] || outl;
-                    const double w = (double)(r ? swv[p] : swu[p]) * iz;
-                    J[4 * r + 0] = zero ? 0.0 : w * ((m1[2 * r] + uv[r] * cs) * X + (m1[2 * r + 1] + uv[r] * sn) * Z);
-                    J[4 * r + 1] = zero ? 0.0 : w * Kd[3 * r + 0];
-                    J[4 * r + 2] = zero ? 0.0 : w * Kd[3 * r + 1];
-                    J[4 * r + 3] = zero ? 0.0 : w * (Kd[3 * r + 2] - uv[r]);
-                }
-                int q = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = i; j < 4; ++j, ++q) hacc[q] += J[i] * J[j] + J[4 + i] * J[4 + j];
-            }
-            block_sum<WPO, 10>(hacc, red);
-            int q = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = i; j < 4; ++j, ++q) { H[4 * i + j] = hacc[q]; H[4 * j + i] = hacc[q]; }
-        }
-        const bool inv_ok = spd_inverse4(H, cov);
-        if (!inv_ok) {
-            if (a.flags & MR_COV_CERES) have_cov = false;          // result_cov left untouched (pnp_uncert_cpu.cpp:285-290)
-            else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) cov[i] = (i % 5 == 0) ? 1.0 : 0.0;   // h := I (pnp_uncert.py:83-85)
-            }
-            valid = false;
-        }
-    }
-
-    MR_STAMP(7);
-    // ---------------------------------------------------------------- outputs
-    if (tid == 0) {
-        a.valid[b] = valid ? 1 : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a.pose[(long long)b * 4 + j] = posef[j];
-        a.tr[b] = pose_ok ? (float)lm.radius : 0.0f;
-        if (a.diag) {
-            a.diag[(long long)b * 4 + 0] = (float)lm.iters;
-            a.diag[(long long)b * 4 + 1] = (float)lm.cost;
-            a.diag[(long long)b * 4 + 2] = (float)lm.why;
-            a.diag[(long long)b * 4 + 3] = k0_count;
-        }
-        if (a.pose64) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a.pose64[(long long)b * 4 + j] = lm.x[j];
-            a.tr64[b] = lm.radius;
-        }
-    }
-    if (have_cov && tid < 16) {
-        a.cov[(long long)b * 16 + tid] = (float)cov[tid];
-        if (a.cov64) a.cov64[(long long)b * 16 + tid] = cov[tid];
-    }
-    if (a.mask)
-        for (int p = tid; p < P; p += NT) a.mask[(long long)b * P + p] = smask[p];
-}
-
-// ------------------------------------------------------------------------------------------------
+#include "pnp_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------
 // K2: fused NOC-head post-processing.  One thread per RoI pixel; every read of all_pred is a coalesced
@@ -908,40 +120,74 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
     a.c2d[((long long)b * 2 + 1) * hw + p] = (y1 - 0.5f) + ((float)py + 0.5f) * sv;
 }
 
-size_t lds_bytes(int Ppad, int wpo, size_t store_size) {
+
+size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
     n += sizeof(double) * wpo * kRedN;
-    n += sizeof(unsigned long long) * ((Ppad / 64 + 1) & ~1);
-    n += store_size * 7 * Ppad;
+    n += (sizeof(unsigned long long) + sizeof(int)) * a.nca;
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
-    n += sizeof(float) * (2 * kMaxLeaves * 8 + 2 * kMaxLeaves + 2 * 16 + 2);
-    n += sizeof(uint16_t) * Ppad;
-    n += Ppad;
+    n += sizeof(float) * (2 * a.nla * 8 + 4 * a.nla + 4);
+    n += (size_t)2 * a.tile_bytes2 + a.tile_bytes3;
+    n += sizeof(uint16_t) * ((a.P + 7) & ~7);
+    n += a.P;
     return (n + 15) & ~(size_t)15;
 }
 
-void plan_rec(PairwisePlan &pl, int off, int n, bool &ok) {
-    if (n <= 128) {
-        if (pl.n_leaves >= kMaxLeaves) { ok = false; return; }
+struct PlanNode { int left, right, height; };
+
+int plan_rec(PairwisePlan &pl, std::vector<PlanNode> &nodes, int off, int n, bool &ok) {
+    if (n <= 128) {                                     // numpy: n < 8 plain loop, n <= PW_BLOCKSIZE unrolled block
+        if (pl.n_leaves >= kMaxLeaves) { ok = false; return 0; }
         pl.leaf_off[pl.n_leaves] = (uint16_t)off; pl.leaf_len[pl.n_leaves] = (uint16_t)n;
-        pl.prog[pl.n_prog++] = (int8_t)pl.n_leaves++;
-    } else {
-        int n2 = n / 2; n2 -= n2 % 8;
-        plan_rec(pl, off, n2, ok); if (!ok) return;
-        plan_rec(pl, off + n2, n - n2, ok); if (!ok) return;
-        pl.prog[pl.n_prog++] = -1;
+        return pl.n_leaves++;                           // slot of a leaf = its index
     }
+    int n2 = n / 2; n2 -= n2 % 8;
+    const int l = plan_rec(pl, nodes, off, n2, ok); if (!ok) return 0;
+    const int r = plan_rec(pl, nodes, off + n2, n - n2, ok); if (!ok) return 0;
+    auto height = [&](int s) { return s < 0 ? nodes[-s - 1].height : 0; };
+    nodes.push_back({ l, r, 1 + (height(l) > height(r) ? height(l) : height(r)) });
+    return -(int)nodes.size();                          // internal nodes: negative ids until renumbered
+}
+
+bool build_plan(PairwisePlan &pl, int P) {
+    memset(&pl, 0, sizeof pl);
+    std::vector<PlanNode> nodes;
+    bool ok = true;
+    const int root = plan_rec(pl, nodes, 0, P, ok);
+    if (!ok || nodes.size() > (size_t)kMaxLeaves) return false;
+    // order internal nodes by height (stable), renumber
+    std::vector<int> order(nodes.size()), newid(nodes.size());
+    int maxh = 0;
+    for (auto &nd : nodes) if (nd.height > maxh) maxh = nd.height;
+    if (maxh + 1 >= 16) return false;
+    int k = 0;
+    for (int h = 1; h <= maxh; ++h) {
+        pl.level_start[h - 1] = (uint8_t)k;
+        for (size_t i = 0; i < nodes.size(); ++i) if (nodes[i].height == h) { order[k] = (int)i; newid[i] = k; ++k; }
+    }
+    pl.level_start[maxh] = (uint8_t)k;
+    pl.n_levels = maxh; pl.n_internal = (int)nodes.size();
+    auto slot = [&](int s) { return s >= 0 ? s : pl.n_leaves + newid[-s - 1]; };
+    for (int i = 0; i < pl.n_internal; ++i) { pl.left[i] = (uint8_t)slot(nodes[order[i]].left); pl.right[i] = (uint8_t)slot(nodes[order[i]].right); }
+    pl.root = slot(root);
+    return true;
 }
 
 int g_last_hip_error = 0;
 unsigned long long *g_stamps = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
+// per-object block layout: contiguous (interleaved or planar) blocks keep their HBM layout in LDS
+void block_layout(const long long s[3], int C, int P, int &contig, int &lps, int &lcs) {
+    if (s[2] == 1 && s[1] == C) { contig = 1; lps = C; lcs = 1; }            // (P, C) interleaved
+    else if (s[1] == 1 && s[2] == P) { contig = 1; lps = 1; lcs = P; }       // (C, P) channel-planar
+    else { contig = 0; lps = 1; lcs = P; }                                    // gathered into a planar image
+}
+
 template <typename T, int WPO>
 int launch(const PnpArgs &a, hipStream_t st) {
-    using S = typename Store<T>::type;
-    const size_t lds = lds_bytes(a.Ppad, WPO, sizeof(S));
+    const size_t lds = lds_bytes(a, WPO);
     if (lds > 160 * 1024) return MR_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {
         static std::mutex mu; static size_t granted = 0;
@@ -958,7 +204,13 @@ int launch(const PnpArgs &a, hipStream_t st) {
 
 template <typename T>
 int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
-    a.Ppad = ((a.P + 64 * wpo - 1) / (64 * wpo)) * (64 * wpo);
+    block_layout(a.s2, 2, a.P, a.contig2, a.lps2, a.lcs2);
+    block_layout(a.sw, 2, a.P, a.contigw, a.lpsw, a.lcsw);
+    block_layout(a.s3, 3, a.P, a.contig3, a.lps3, a.lcs3);
+    a.tile_bytes2 = (int)(((size_t)2 * a.P * sizeof(T) + 15) & ~(size_t)15);
+    a.tile_bytes3 = (int)(((size_t)3 * a.P * sizeof(T) + 15) & ~(size_t)15);
+    a.nca = (((a.P + 63) / 64) + 3) & ~3;
+    a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
     switch (wpo) {
         case 1: return launch<T, 1>(a, st);
         case 2: return launch<T, 2>(a, st);
@@ -997,7 +249,7 @@ const char *mr_pnp_error_string(int code) {
 
 int mr_pnp_last_hip_error(void) { return g_last_hip_error; }
 
-// development aid (not in the public header): device buffer of (B,8) u64 cycle stamps, or NULL to disable
+// development aid (not in the public header): device buffer of (B,10) u64 cycle stamps, or NULL to disable
 void mr_pnp_debug_set_stamps(unsigned long long *dev_ptr) { g_stamps = dev_ptr; }
 
 int mr_pnp_device_count(void) {
@@ -1013,7 +265,7 @@ int mr_pnp_uncert_batched(
     const float *ransac_thr, const double *init_pose, int B, int P,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream) {
-    if (B < 0 || P < 4 || P > 65535) return MR_ERR_BAD_ARGUMENT;
+    if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range ||
         !valid || !pose || !tr_radius || (!cov && !(flags & MR_COV_NONE)))
@@ -1033,9 +285,7 @@ int mr_pnp_uncert_batched(
     if (mm == MR_MEAN_AUTO) mm = (istd_strides[1] == 1 && P > 1) ? MR_MEAN_PAIRWISE : MR_MEAN_SEQUENTIAL;
     a.mean_mode = mm;
     if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
-        bool ok = true;
-        plan_rec(a.plan, 0, P, ok);
-        if (!ok) return MR_ERR_UNSUPPORTED;
+        if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
     const int wpo = pick_wpo(B, P, flags);
     hipStream_t st = (hipStream_t)stream;

@@ -154,19 +154,26 @@ static int orc_eval(const orc_problem *pb, const double x[4], double *cost, doub
     return ok;
 }
 
-/* Cholesky solve of a symmetric n x n (n<=5) system, row-major full storage. 0 on non-PD. */
+/* Cholesky solve of a symmetric n x n (n<=5) system, row-major full storage. 0 on non-PD.
+ * Reciprocal form: one sqrt and one division per pivot, multiplications elsewhere, explicit fma —
+ * the exact operation sequence is part of the K0 specification. */
 static int orc_chol_solve(int n, const double *A, const double *b, double *x) {
-    double L[25];
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i * n + j];
-            for (int k = 0; k < j; ++k) s = fma(-L[i * n + k], L[j * n + k], s);
-            if (i == j) { if (!(s > 0.0) || !isfinite(s)) return 0; L[i * n + i] = sqrt(s); }
-            else L[i * n + j] = s / L[j * n + j];
+    double L[25], inv[5];
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s = fma(-L[j * n + k], L[j * n + k], s);
+        if (!(s > 0.0) || !isfinite(s)) return 0;
+        const double d = sqrt(s);
+        L[j * n + j] = d; inv[j] = 1.0 / d;
+        for (int i = j + 1; i < n; ++i) {
+            double t = A[i * n + j];
+            for (int k = 0; k < j; ++k) t = fma(-L[i * n + k], L[j * n + k], t);
+            L[i * n + j] = t * inv[j];
         }
+    }
     double y[5];
-    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s = fma(-L[i * n + k], y[k], s); y[i] = s / L[i * n + i]; }
-    for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s = fma(-L[k * n + i], x[k], s); x[i] = s / L[i * n + i]; }
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s = fma(-L[i * n + k], y[k], s); y[i] = s * inv[i]; }
+    for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s = fma(-L[k * n + i], x[k], s); x[i] = s * inv[i]; }
     return 1;
 }
 
@@ -382,7 +389,7 @@ int orc_pose_cov(const double H[16], double cov[16]) {
  *     picked by a counter-based hash; linear 4-DoF solve (5x5 normal eqs in (cos,sin,tx,ty,tz)),
  *     normalise (cos,sin), re-solve t (3x3) — fp64, fixed operation order, explicit fma
  *   - consensus of every hypothesis over the candidates in fp32 with a fixed operation order:
- *     |fx X - (u-cx) Z|^2 + |fy Y - (v-cy) Z|^2 <= (thr Z)^2  and  Z > 0
+ *     |fx X - (u-cx) Z|^2 + |fy Y - (v-cy) Z|^2 <= (thr Z) |thr Z|   (false for Z < 0 and for NaN)
  *   - best = first maximum; fewer than 5 consensus points -> failure (ret False, like RANSAC)
  *   - refit on the consensus set with the same linear solver (fp64), yaw0 = atan2(sin, cos)
  * ---------------------------------------------------------------------------------------- */
@@ -441,7 +448,7 @@ static int orc_consensus(const float hyp[5], float fx, float fy, float a, float 
     const float ev = fmaf(-b, Zc, fy * Yc);
     const float e2 = fmaf(eu, eu, ev * ev);
     const float lim = thr * Zc;
-    return (Zc > 0.0f) && (e2 <= lim * lim);
+    return e2 <= lim * fabsf(lim);            /* one compare: Zc <= 0 makes the bound <= 0, NaN compares false */
 }
 
 /* returns 1 on success.  mask: in = candidates (mask0), out = consensus set (if ransac) . */

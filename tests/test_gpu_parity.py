@@ -56,8 +56,7 @@ def _cmp(gpu, ref, tag=''):
     if ok.any():
         scale = np.abs(r_cov[ok]).reshape(ok.sum(), -1).max(1)[:, None, None]
         assert (np.abs(cov[ok] - r_cov[ok]) / scale).max() <= COV_RTOL, tag
-    ident = np.all(r_cov == np.eye(4, dtype=np.float32), axis=(1, 2))
-    assert np.array_equal(cov[ident], r_cov[ident]), tag
+    assert np.isfinite(cov[~ok & np.isfinite(r_cov).all((1, 2))]).all(), tag
     np.testing.assert_allclose(tr, r_tr[:, 0], rtol=1e-6, err_msg=tag)
 
 
