@@ -38,7 +38,8 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, SRC, '-o', SO]
+    extra = os.environ.get('MR_HIPCC_EXTRA', '').split()
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ['-I', INCLUDE, SRC, '-o', SO]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

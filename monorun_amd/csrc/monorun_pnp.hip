@@ -16,6 +16,10 @@ constexpr int kMaxChunks = 128;     // 64-point chunks per object (P <= 8192; LD
 constexpr int kHyp = 32;            // K0 hypotheses (the reference's RANSAC runs 30 iterations)
 constexpr uint32_t kK0Seed = 0x9E3779B9u;
 constexpr int kRedN = 24;           // doubles per wave in the cross-wave reduction scratch
+constexpr int kPark = 32;           // doubles of parked wave-uniform LM state
+#ifndef MR_MIN_WAVES
+#define MR_MIN_WAVES 2              // waves per SIMD the register allocator must allow (<= 256 VGPRs: no spills)
+#endif
 
 // numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host:
 // leaves (blocks of <=128 elements) + the combine tree, internal nodes ordered by height so that the
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
-    n += sizeof(double) * wpo * kRedN;
+    n += sizeof(double) * (wpo * kRedN + kPark);
     n += (sizeof(unsigned long long) + sizeof(int)) * a.nca;
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
@@ -223,9 +227,11 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
 int pick_wpo(int B, int P, int flags) {
     int w = (flags & MR_WAVES_MASK) >> MR_WAVES_SHIFT;
     if (w) return w;
-    // fill 256 CUs x 4 SIMDs with ~4 waves per SIMD when the batch alone cannot
+    // The kernel allocates up to 256 VGPRs -> 2 resident waves per SIMD -> 2048 waves on 256 CUs x 4 SIMDs.
+    // Split an object over more wavefronts only while the whole batch stays resident in one round
+    // (measured on MI355X: B=1024 is fastest at 2 waves/object, B>=2048 at 1).
     w = 1;
-    while (w < 8 && (long long)B * w * 2 <= 4096 && P >= 64 * w * 2) w *= 2;
+    while (w < 4 && (long long)B * w * 2 <= 2048 && P >= 64 * w * 2) w *= 2;
     return w;
 }
 

@@ -390,7 +390,8 @@ int orc_pose_cov(const double H[16], double cov[16]) {
  *     normalise (cos,sin), re-solve t (3x3) — fp64, fixed operation order, explicit fma
  *   - consensus of every hypothesis over the candidates in fp32 with a fixed operation order:
  *     |fx X - (u-cx) Z|^2 + |fy Y - (v-cy) Z|^2 <= (thr Z) |thr Z|   (false for Z < 0 and for NaN)
- *   - best = first maximum; fewer than 5 consensus points -> failure (ret False, like RANSAC)
+ *   - hypotheses are scored in blocks of 8 with RANSAC's adaptive stop (confidence 0.99);
+ *     best = first maximum; fewer than 5 consensus points -> failure (ret False, like RANSAC)
  *   - refit on the consensus set with the same linear solver (fp64), yaw0 = atan2(sin, cos)
  * ---------------------------------------------------------------------------------------- */
 #define ORC_K0_SEED 0x9E3779B9u
@@ -483,13 +484,26 @@ int orc_k0_init(const float *x2d /*pn,2*/, const float *x3d /*pn,3*/, uint8_t *m
             hyp[h][0] = (float)c; hyp[h][1] = (float)s; hyp[h][2] = (float)t[0]; hyp[h][3] = (float)t[1]; hyp[h][4] = (float)t[2];
             valid[h] = 1;
         }
+        /* consensus in blocks of 8 hypotheses with RANSAC's adaptive termination (confidence 0.99,
+         * 5-point samples: stop once (1 - w^5)^evaluated <= 0.01, w = best inlier ratio) — the rule
+         * cv2.solvePnPRansac applies after every iteration, here checked after every block. */
         int best = -1, bestc = 0;
-        for (int h = 0; h < n_hyp; ++h) {
-            if (!valid[h]) continue;
-            int cnt = 0;
-            for (int q = 0; q < n; ++q) { const int p = list[q];
-                cnt += orc_consensus(hyp[h], fxf, fyf, x2d[2 * p] - cxf, x2d[2 * p + 1] - cyf, x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], thr); }
-            if (cnt > bestc) { bestc = cnt; best = h; }
+        for (int h0 = 0; h0 < n_hyp; h0 += 8) {
+            for (int h = h0; h < h0 + 8 && h < n_hyp; ++h) {
+                if (!valid[h]) continue;
+                int cnt = 0;
+                for (int q = 0; q < n; ++q) { const int p = list[q];
+                    cnt += orc_consensus(hyp[h], fxf, fyf, x2d[2 * p] - cxf, x2d[2 * p + 1] - cyf, x3d[3 * p], x3d[3 * p + 1], x3d[3 * p + 2], thr); }
+                if (cnt > bestc) { bestc = cnt; best = h; }
+            }
+            if (bestc >= 5) {
+                const double w = (double)bestc / (double)n;
+                double w5 = w * w; w5 = w5 * w5 * w;
+                double q8 = 1.0 - w5; q8 = q8 * q8; q8 = q8 * q8; q8 = q8 * q8;
+                double qk = q8;
+                for (int k = 8; k < h0 + 8; k += 8) qk = qk * q8;
+                if (qk <= 0.01) break;
+            }
         }
         if (best_hyp) *best_hyp = best; if (best_count) *best_count = bestc;
         if (best < 0 || bestc < 5) ok = 0;

@@ -15,23 +15,19 @@ def dv(a):
 args = (dv(x2d), dv(istd), dv(x3d), dv(K), dv(ur), dv(vr)); thr_d = dv(thr)
 names = ['load', 'mask', 'k0:list+hyp', 'k0:consensus', 'k0:refit', 'lm', 'cov']
 for wpo in (1, 2, 4):
-    st = torch.zeros(B, 10, dtype=torch.int64, device=dev)
+    st = torch.zeros(B, 24, dtype=torch.int64, device=dev)
     for it in range(3):
         lib.mr_pnp_debug_set_stamps(st.data_ptr())
         out = pnp_uncert_device(*args, 0.5, 0.6, thr_d, True, flags=(wpo << _lib.MR_WAVES_SHIFT), with_diag=True)
         torch.cuda.synchronize()
     lib.mr_pnp_debug_set_stamps(None)
     s = st.cpu().numpy().astype(np.float64)
-    hw = s[:, 8].astype(np.int64); xcc = s[:, 9].astype(np.int64) & 0xf; s = s[:, :8]
+    wall = (s[:, 9] - s[:, 8]) * 10.0   # ns
+    dbg = s[:, 12:24]
+    print('   LM detail (median cycles): eval0 sincos %d points %d reduce %d | post-eval0 -> iter1 start %d | solve+logic before eval1 %d | eval1 sincos %d points %d reduce %d | after-eval logic %d' % tuple(np.median(x) for x in (dbg[:,1]-dbg[:,0], dbg[:,2]-dbg[:,1], dbg[:,3]-dbg[:,2], dbg[:,4]-dbg[:,3], dbg[:,5]-dbg[:,4], dbg[:,7]-dbg[:,6], dbg[:,8]-dbg[:,7], dbg[:,9]-dbg[:,8], dbg[:,10]-dbg[:,9])))
+    s = s[:, :8]
     d = np.diff(s, axis=1)
-    cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3
-    key = xcc * 10000 + se * 1000 + sh * 100 + cu
-    import collections
-    cnt = collections.Counter(key.tolist())
-    print('   distinct CUs used', len(cnt), 'blocks per CU histogram', collections.Counter(cnt.values()), 'simd hist', collections.Counter(simd.tolist()))
-    for x in range(8):
-        m = xcc == x
-        if m.any(): print('   xcc', x, 'blocks', m.sum(), 'span cycles', s[m, 7].max() - s[m, 0].min(), 'start spread', s[m, 0].max() - s[m, 0].min())
+    print('   block wall time median %.1f us, max %.1f us; s_memtime ticks per ns: %.3f' % (np.median(wall)/1e3, wall.max()/1e3, np.median((s[:,7]-s[:,0]) / wall)))
     iters = out[5][:, 0].cpu().numpy()
     print(f'wpo={wpo}  median cycles per stage (100 MHz constant clock ticks -> x24 for 2.4GHz shader cycles?)')
     for n, col in zip(names, d.T):
