@@ -80,11 +80,17 @@ def cpu_baseline(np_inputs, seconds):
     one = dict(value=n1 * reps / el, unit='solves/s', cores=1, kind='port',
                sample=f'first {n1} objects of the config-2 batch x {reps} repeats, {el:.1f} s, single thread '
                       '(the reference runs objects serially with Ceres num_threads=1)')
-    nthr = orc.max_threads()
+    nthr = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                               # containers: honour the cgroup CPU quota (e.g. "1600000 100000" = 16 cores)
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            nthr = max(1, min(nthr, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001
+        pass
     t0 = time.perf_counter()
     reps = 0
     while True:
-        orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, num_threads=0)
+        orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, num_threads=nthr)
         reps += 1
         el = time.perf_counter() - t0
         if el >= seconds * 0.4 or reps >= 200:
