@@ -265,3 +265,23 @@ def test_full_size_properties(dev):
     assert np.abs(p3[ok] - pose[ok]).max() < 5e-2 and (d3[ok, 0] <= 3).mean() > 0.95
     # the LM only ever lowers the cost it was given
     assert (diag[valid, 1] >= 0).all()
+
+
+def test_stress_shape_fp16_56x56(dev, orc):
+    """BASELINE config 5 shape (56x56 = 3136 correspondences, fp16 storage of X3d / istd / x2d) at a
+    batch the oracle finishes in seconds: 88 KB fp32-equivalent tiles (44 KB as fp16) in LDS, the
+    32-leaf numpy pairwise tree, 49 points per lane at one wave per object."""
+    b = syn.make_batch(B=24, hw=56, seed=4321)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    # fp16 storage: pixel coordinates up to ~1442 keep 1-px resolution in fp16 (SURVEY H6) — the oracle sees the same rounded values
+    h2, hw_, h3 = x2d.astype(np.float16), istd.astype(np.float16), x3d.astype(np.float16)
+    mk = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1)).transpose(0, 2, 1)      # keep the planar strides after astype
+    h2, hw_, h3 = mk(h2), mk(hw_), mk(h3)
+    assert h2.strides == (2 * 3136 * 2, 2, 3136 * 2)
+    ref = orc.u2d_pnp(mk(h2.astype(np.float32)), mk(hw_.astype(np.float32)), mk(h3.astype(np.float32)), K, ur, vr, 0.5, 0.6, thr, True,
+                      return_diag=True, num_threads=0)
+    for wpo in (1, 2, 4):
+        _cmp(_run(dev, h2, hw_, h3, K, ur, vr, thr, flags=wpo << 8), ref, f'fp16 56x56 wpo={wpo}')
+    # fp32 storage of the same shape
+    ref32 = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+    _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, thr), ref32, 'fp32 56x56')
