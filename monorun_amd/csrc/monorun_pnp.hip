@@ -15,10 +15,9 @@ constexpr int kMaxLeaves = 64;      // numpy pairwise-sum leaves (blocks of <=12
 constexpr int kMaxChunks = 128;     // 64-point chunks per object (P <= 8192; LDS caps P well below that)
 constexpr int kHyp = 32;            // K0 hypotheses (the reference's RANSAC runs 30 iterations)
 constexpr uint32_t kK0Seed = 0x9E3779B9u;
-constexpr int kRedN = 24;           // doubles per wave in the cross-wave reduction scratch
-constexpr int kPark = 32;           // doubles of parked wave-uniform LM state
+constexpr int kRedN = 32;           // doubles per wave in the cross-wave reduction scratch
 #ifndef MR_MIN_WAVES
-#define MR_MIN_WAVES 2              // waves per SIMD the register allocator must allow (<= 256 VGPRs: no spills)
+#define MR_MIN_WAVES 3              // waves per SIMD the register allocator must allow (<= 168 VGPRs, no spills)
 #endif
 
 // numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host:
@@ -127,7 +126,7 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
-    n += sizeof(double) * (wpo * kRedN + kPark);
+    n += sizeof(double) * 2 * wpo * kRedN;
     n += (sizeof(unsigned long long) + sizeof(int)) * a.nca;
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
@@ -218,6 +217,7 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
     switch (wpo) {
         case 1: return launch<T, 1>(a, st);
         case 2: return launch<T, 2>(a, st);
+        case 3: return launch<T, 3>(a, st);
         case 4: return launch<T, 4>(a, st);
         case 8: return launch<T, 8>(a, st);
         default: return MR_ERR_BAD_ARGUMENT;
@@ -227,11 +227,12 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
 int pick_wpo(int B, int P, int flags) {
     int w = (flags & MR_WAVES_MASK) >> MR_WAVES_SHIFT;
     if (w) return w;
-    // The kernel allocates up to 256 VGPRs -> 2 resident waves per SIMD -> 2048 waves on 256 CUs x 4 SIMDs.
-    // Split an object over more wavefronts only while the whole batch stays resident in one round
-    // (measured on MI355X: B=1024 is fastest at 2 waves/object, B>=2048 at 1).
+    // The kernel is built for 3 resident waves per SIMD (<= 168 VGPRs) -> 3072 waves on 256 CUs x 4 SIMDs; a lone
+    // wave issues only ~1 VALU instruction per 7 cycles, so small batches are split over more wavefronts per
+    // object (measured on MI355X: B = 1024 is fastest at 4 waves/object, B = 8192 at 2).
     w = 1;
-    while (w < 4 && (long long)B * w * 2 <= 2048 && P >= 64 * w * 2) w *= 2;
+    while (w < 4 && (long long)B * w * 2 <= 4096 && P >= 64 * w * 2) w *= 2;
+    if (w == 1 && P >= 256) w = 2;
     return w;
 }
 
