@@ -285,3 +285,13 @@ def test_stress_shape_fp16_56x56(dev, orc):
     # fp32 storage of the same shape
     ref32 = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
     _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, thr), ref32, 'fp32 56x56')
+
+
+@pytest.mark.parametrize('seed,B', [(1234, 1024), (1, 256), (2, 256), (20260928, 256)])
+def test_bench_workload_matches_oracle_object_by_object(dev, orc, seed, B):
+    """The exact bench.py workload (config 2, seed 1234, 1024 objects, planar fp32) and three more seeds:
+    every object against the oracle (mask/K0 bit-exact, pose 1e-4, cov 1e-5, same LM iteration counts)."""
+    b = syn.make_batch(B=B, seed=seed)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+    _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, thr), ref, f'seed={seed} B={B}')

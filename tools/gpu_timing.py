@@ -9,7 +9,7 @@ def dv(a):
 for B in [int(x) for x in os.environ.get('QBS', '1024').split(',')]:
     b = syn.make_batch(B=B, seed=1234)
     x2d, istd, x3d, K, ur, vr, thr = [dv(a) for a in syn.pnp_boundary(b, planar=True)]
-    for wpo in (0, 1, 2, 3, 4, 8):
+    for wpo in [int(x) for x in os.environ.get('QW', '0,1,2,3,4,8').split(',')]:
         L = PnPLaunch(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, flags=(wpo << 8))
         for _ in range(5): L.run()
         torch.cuda.synchronize()
