@@ -129,6 +129,19 @@ int mr_noc_decode_batched(
     float *dims, float *dims_var, float *ransac_thr,
     void *stream);
 
+/*
+ * N1: rotated-BEV NMS of the pose consumers — replaces mmdet3d.ops.iou3d.nms_gpu as called by
+ * multiclass_3d_result_nms (monorun/models/roi_heads/monorun_roi_head.py:619-655).
+ *   boxes_xyxyr (total,5) f32 [x1, y1, x2, y2, ry] (xywhr2xyxyr, :657-677), scores (total) f32,
+ *   offsets (groups+1) i32: group g owns rows [offsets[g], offsets[g+1]) (one group per class), max_group =
+ *   largest group size (<= 512).  A box is suppressed when its rotated IoU with an already kept, higher
+ *   scoring box of its group exceeds thr (score ties: lower index first).
+ *   keep (total) i64: kept indices LOCAL to the group, descending score, written at keep[offsets[g] ...];
+ *   num_keep (groups) i32.
+ */
+int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int32_t *offsets, int groups, int max_group,
+                       float thr, int64_t *keep, int32_t *num_keep, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,124 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// N1: rotated-BEV NMS, the consumer that follows the PnP (monorun_roi_head.py:619-655 calls
+// mmdet3d.ops.iou3d.nms_gpu — third-party, not in the reference tree; restated from its published algorithm:
+// sort by score, rotated-rectangle IoU = overlap / max(area_a + area_b - overlap, 1e-8), greedy
+// suppression of IoU > thr).  One workgroup per class group (n <= kNmsMax boxes).
+constexpr int kNmsMax = 512;
+
+struct NmsBox { float cx, cy; float px[4], py[4]; float area; };   // CCW corners relative to nothing (absolute)
+
+// length-weighted boundary integral of the part of segment p->p+d that lies inside the convex CCW polygon q
+// (Cyrus-Beck parametric clipping, no dynamic arrays); CLOSED selects >= (boundary counts) or > (it does not),
+// so that an edge shared by both rectangles is counted exactly once.
+template <bool CLOSED>
+__device__ __forceinline__ float edge_inside_area(float px, float py, float dx, float dy, const float (&qx)[4], const float (&qy)[4]) {
+    float t0 = 0.0f, t1 = 1.0f;
+    bool empty = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ax = qx[e], ay = qy[e], bx = qx[(e + 1) & 3], by = qy[(e + 1) & 3];
+        const float nx = -(by - ay), ny = bx - ax;                 // inward normal of a CCW edge
+        const float f0 = nx * (px - ax) + ny * (py - ay);
+        const float den = nx * dx + ny * dy;
+        if (den > 0.0f) t0 = fmaxf(t0, -f0 / den);
+        else if (den < 0.0f) t1 = fminf(t1, -f0 / den);
+        else if (CLOSED ? (f0 < 0.0f) : (f0 <= 0.0f)) empty = true;
+    }
+    if (empty || !(t1 > t0)) return 0.0f;
+    const float x0 = px + t0 * dx, y0 = py + t0 * dy, x1 = px + t1 * dx, y1 = py + t1 * dy;
+    return 0.5f * (x0 * y1 - x1 * y0);
+}
+
+__device__ __forceinline__ float rotated_iou(const NmsBox &a, const NmsBox &b) {
+    // work relative to a's centre to keep fp32 cancellation small
+    float ax[4], ay[4], bx[4], by[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ax[i] = a.px[i] - a.cx; ay[i] = a.py[i] - a.cy; bx[i] = b.px[i] - a.cx; by[i] = b.py[i] - a.cy; }
+    float ov = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ov += edge_inside_area<true>(ax[i], ay[i], ax[(i + 1) & 3] - ax[i], ay[(i + 1) & 3] - ay[i], bx, by);
+        ov += edge_inside_area<false>(bx[i], by[i], bx[(i + 1) & 3] - bx[i], by[(i + 1) & 3] - by[i], ax, ay);
+    }
+    ov = fmaxf(ov, 0.0f);
+    return ov / fmaxf(a.area + b.area - ov, 1e-8f);
+}
+
+__global__ void __launch_bounds__(256) nms_bev_kernel(const float *boxes, const float *scores, const int *offsets, float thr,
+                                                      long long *keep, int *num_keep) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int off = offsets[g], n = offsets[g + 1] - off;
+    extern __shared__ __align__(16) unsigned char smem[];
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    float *skey = (float *)smem;                         // [np2]
+    int *sidx = (int *)(skey + np2);                     // [np2]
+    NmsBox *sbox = (NmsBox *)(sidx + np2);               // [n] in sorted order
+    const int nw = (n + 31) >> 5;
+    unsigned *srow = (unsigned *)(sbox + n);             // [n][nw] suppression bits (j > i, IoU > thr)
+    if (n <= 0) { if (tid == 0) num_keep[g] = 0; return; }
+    for (int i = tid; i < np2; i += 256) { skey[i] = (i < n) ? scores[off + i] : -__int_as_float(0x7f800000); sidx[i] = (i < n) ? i : 0x7fffffff; }
+    __syncthreads();
+    // bitonic sort: descending score, ties by ascending index; NaN scores sort last
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float ki = skey[i], kl = skey[l]; const int ii = sidx[i], il = sidx[l];
+                    // "i before l" in the final order
+                    const bool i_first = (ki > kl) || (ki == kl && ii < il) || (kl != kl && ki == ki);
+                    const bool up = (i & k) == 0;
+                    if (up ? !i_first : i_first) { skey[i] = kl; skey[l] = ki; sidx[i] = il; sidx[l] = ii; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 256) {
+        const float *b = boxes + (long long)(off + sidx[i]) * 5;
+        const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3], ang = b[4];
+        NmsBox nb;
+        nb.cx = 0.5f * (x1 + x2); nb.cy = 0.5f * (y1 + y2);
+        const float hw = 0.5f * (x2 - x1), hh = 0.5f * (y2 - y1);
+        float sn, cs; sincosf(ang, &sn, &cs);
+        const float ddx[4] = { -hw, hw, hw, -hw }, ddy[4] = { -hh, -hh, hh, hh };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { nb.px[c] = nb.cx + ddx[c] * cs + ddy[c] * sn; nb.py[c] = nb.cy - ddx[c] * sn + ddy[c] * cs; }
+        if (hw * hh < 0.0f) {                               // keep the corner order counter-clockwise
+            const float tx = nb.px[1], ty = nb.py[1]; nb.px[1] = nb.px[3]; nb.py[1] = nb.py[3]; nb.px[3] = tx; nb.py[3] = ty;
+        }
+        nb.area = fabsf((x2 - x1) * (y2 - y1));
+        sbox[i] = nb;
+    }
+    __syncthreads();
+    for (int t = tid; t < n * nw; t += 256) {
+        const int i = t / nw, w = t - i * nw;
+        unsigned bits = 0;
+        const NmsBox a = sbox[i];
+        for (int jj = 0; jj < 32; ++jj) {
+            const int j = w * 32 + jj;
+            if (j > i && j < n && rotated_iou(a, sbox[j]) > thr) bits |= 1u << jj;
+        }
+        srow[t] = bits;
+    }
+    __syncthreads();
+    if (tid < 64) {                                          // one wave, wave-synchronous greedy pass
+        unsigned removed = 0;                                // lane w holds word w of the removed set (nw <= 16)
+        int kept = 0;
+        for (int i = 0; i < n; ++i) {
+            const unsigned word = __builtin_amdgcn_readlane(removed, i >> 5);
+            if (!((word >> (i & 31)) & 1u)) {
+                if (tid == 0) keep[off + kept] = (long long)sidx[i];
+                ++kept;
+                if (tid < nw) removed |= srow[i * nw + tid];
+            }
+        }
+        if (tid == 0) num_keep[g] = kept;
+    }
+}
+
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
     n += sizeof(double) * 2 * wpo * kRedN;
@@ -331,6 +449,20 @@ int mr_noc_decode_batched(
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     const int hw = h * w;
     hipLaunchKernelGGL(noc_decode_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
+int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int32_t *offsets, int groups, int max_group,
+                       float thr, int64_t *keep, int32_t *num_keep, void *stream) {
+    if (groups < 0 || max_group < 0) return MR_ERR_BAD_ARGUMENT;
+    if (groups == 0) return MR_OK;
+    if (!offsets || !keep || !num_keep || (max_group > 0 && (!boxes_xyxyr || !scores))) return MR_ERR_BAD_ARGUMENT;
+    if (max_group > kNmsMax) return MR_ERR_UNSUPPORTED;
+    int np2 = 1; while (np2 < max_group) np2 <<= 1;
+    const size_t lds = (size_t)np2 * 8 + (size_t)max_group * sizeof(NmsBox) + (size_t)max_group * ((max_group + 31) / 32) * 4 + 16;
+    hipLaunchKernelGGL(nms_bev_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, boxes_xyxyr, scores, (const int *)offsets, thr,
+                       (long long *)keep, (int *)num_keep);
     HIP_TRY(hipGetLastError());
     return MR_OK;
 }

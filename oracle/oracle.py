@@ -269,3 +269,99 @@ def cov_correction(cov, t_vec, ref_length=1.6, ref_focal_y=722, target_std=0.15)
     sd = np.float32(ref_length * ref_focal_y * target_std)
     dist = np.linalg.norm(t_vec.astype(np.float32), axis=1)
     return cov * np.square(sd / dist).reshape(-1, 1, 1)
+
+
+# ------------------------------------------------------------------ N1: consumers of the pose -----
+# Rotated-BEV NMS.  The reference calls mmdet3d.ops.iou3d.nms_gpu (third-party, not in the tree, version
+# pinned only by INSTALL.md's mmdet3d 0.8.0 line) at monorun_roi_head.py:638-639 on boxes
+# [x1, y1, x2, y2, ry] built by xywhr2xyxyr (:657-677).  Restated from the published algorithm of
+# mmdet3d/ops/iou3d (sort by score, pairwise rotated-rectangle IoU by polygon clipping, greedy suppression
+# of IoU > thr, IoU = overlap / max(area_a + area_b - overlap, 1e-8)); fp64, Sutherland-Hodgman clipping.
+def _bev_corners(b):
+    x1, y1, x2, y2, ang = [float(v) for v in b]
+    cx, cy, hw, hh = 0.5 * (x1 + x2), 0.5 * (y1 + y2), 0.5 * (x2 - x1), 0.5 * (y2 - y1)
+    c, s = np.cos(ang), np.sin(ang)
+    pts = []
+    for dx, dy in ((-hw, -hh), (hw, -hh), (hw, hh), (-hw, hh)):
+        # mmdet3d rotate_around_center: x' = dx*cos + dy*sin, y' = -dx*sin + dy*cos
+        pts.append((cx + dx * c + dy * s, cy - dx * s + dy * c))
+    return pts
+
+
+def _poly_area(p):
+    a = 0.0
+    for i in range(len(p)):
+        x0, y0 = p[i]
+        x1, y1 = p[(i + 1) % len(p)]
+        a += x0 * y1 - x1 * y0
+    return 0.5 * a
+
+
+def _clip(subject, clipper):
+    """Sutherland-Hodgman: clip polygon `subject` by convex polygon `clipper` (both CCW)."""
+    out = subject
+    for i in range(len(clipper)):
+        ax, ay = clipper[i]
+        bx, by = clipper[(i + 1) % len(clipper)]
+        inp, out = out, []
+        if not inp:
+            break
+        def side(p):
+            return (bx - ax) * (p[1] - ay) - (by - ay) * (p[0] - ax)
+        for j in range(len(inp)):
+            p, q = inp[j], inp[(j + 1) % len(inp)]
+            sp, sq = side(p), side(q)
+            if sp >= 0:
+                out.append(p)
+            if (sp >= 0) != (sq >= 0):
+                t = sp / (sp - sq)
+                out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+    return out
+
+
+def rotated_iou_bev(a, b):
+    pa, pb = _bev_corners(a), _bev_corners(b)
+    if _poly_area(pa) < 0:
+        pa = pa[::-1]
+    if _poly_area(pb) < 0:
+        pb = pb[::-1]
+    inter = _clip(pa, pb)
+    ov = abs(_poly_area(inter)) if len(inter) >= 3 else 0.0
+    sa = abs((a[2] - a[0]) * (a[3] - a[1]))
+    sb = abs((b[2] - b[0]) * (b[3] - b[1]))
+    return ov / max(sa + sb - ov, 1e-8)
+
+
+def nms_bev(boxes_xyxyr, scores, thr):
+    """Greedy rotated NMS; returns kept indices into the input, in descending-score order
+    (ties: lower index first)."""
+    boxes = np.asarray(boxes_xyxyr, np.float64)
+    scores = np.asarray(scores, np.float64)
+    order = sorted(range(len(scores)), key=lambda i: (-scores[i], i))
+    keep, dead = [], set()
+    for ii, i in enumerate(order):
+        if i in dead:
+            continue
+        keep.append(i)
+        for j in order[ii + 1:]:
+            if j not in dead and rotated_iou_bev(boxes[i], boxes[j]) > thr:
+                dead.add(j)
+    return np.array(keep, np.int64)
+
+
+def xywhr2xyxyr(b):
+    """monorun_roi_head.py:657-677."""
+    b = np.asarray(b)
+    out = np.zeros_like(b)
+    out[:, 0] = b[:, 0] - b[:, 2] / 2
+    out[:, 1] = b[:, 1] - b[:, 3] / 2
+    out[:, 2] = b[:, 0] + b[:, 2] / 2
+    out[:, 3] = b[:, 1] + b[:, 3] / 2
+    out[:, 4] = b[:, 4]
+    return out
+
+
+def score_head_inputs(yaw, t_vec, pose_cov, dims):
+    """mlp_score_head.py:101-103: [yaw, t, tril(cov) in torch.tril_indices(4,4) order, dims] -> (n, 17)."""
+    r, c = np.tril_indices(4)
+    return np.concatenate([yaw, t_vec, pose_cov[:, r, c], dims], axis=1)

@@ -1,0 +1,110 @@
+"""N1: the consumers of the pose.  CPU tests pin the oracle's rotated-IoU / NMS restatement
+(closed forms, symmetry, Monte-Carlo areas); GPU tests compare the HIP kernel with it."""
+import numpy as np
+import pytest
+import torch
+
+
+def _rand_boxes(rng, n, spread=20.0):
+    """BEV boxes like the pipeline's: [x1, y1, x2, y2, ry] from centre (x, z), size (l, w), yaw."""
+    c = rng.uniform(-spread, spread, (n, 2))
+    lw = np.stack([rng.uniform(1.5, 4.5, n), rng.uniform(0.5, 2.0, n)], 1)
+    ry = rng.uniform(-np.pi, np.pi, n)
+    return np.concatenate([c - lw / 2, c + lw / 2, ry[:, None]], 1).astype(np.float32)
+
+
+def test_rotated_iou_closed_forms(orc):
+    assert abs(orc.rotated_iou_bev([0, 0, 2, 2, 0], [1, 1, 3, 3, 0]) - 1 / 7) < 1e-12
+    assert abs(orc.rotated_iou_bev([0, 0, 2, 2, 0.3], [0, 0, 2, 2, 0.3]) - 1.0) < 1e-12          # identical boxes
+    assert orc.rotated_iou_bev([0, 0, 1, 1, 0], [5, 5, 6, 6, 1.0]) == 0.0                          # disjoint
+    oct_area = 8 * (np.sqrt(2) - 1)                                                                # 2x2 square vs itself rotated 45 deg
+    assert abs(orc.rotated_iou_bev([0, 0, 2, 2, np.pi / 4], [0, 0, 2, 2, 0]) - oct_area / (8 - oct_area)) < 1e-12
+    assert abs(orc.rotated_iou_bev([0, 0, 4, 2, np.pi / 2], [1, -1, 3, 3, 0]) - 1.0) < 1e-12       # 4x2 rotated 90 deg == 2x4
+    rng = np.random.default_rng(0)
+    b = _rand_boxes(rng, 40, spread=4.0)
+    for i in range(0, 40, 2):                                                                      # symmetry + Monte-Carlo area
+        iou = orc.rotated_iou_bev(b[i], b[i + 1])
+        assert abs(iou - orc.rotated_iou_bev(b[i + 1], b[i])) < 1e-12
+    pts = rng.uniform(-8, 8, (400000, 2))
+    def inside(bx, p):
+        cx, cy, hw, hh = (bx[0] + bx[2]) / 2, (bx[1] + bx[3]) / 2, (bx[2] - bx[0]) / 2, (bx[3] - bx[1]) / 2
+        c, s = np.cos(bx[4]), np.sin(bx[4])
+        dx, dy = p[:, 0] - cx, p[:, 1] - cy
+        lx, ly = dx * c - dy * s, dx * s + dy * c          # inverse of x' = dx c + dy s, y' = -dx s + dy c
+        return (np.abs(lx) <= hw) & (np.abs(ly) <= hh)
+    for i in range(0, 10, 2):
+        ia, ib = inside(b[i], pts), inside(b[i + 1], pts)
+        mc = (ia & ib).sum() / max((ia | ib).sum(), 1)
+        assert abs(mc - orc.rotated_iou_bev(b[i], b[i + 1])) < 0.02
+
+
+def test_nms_oracle_properties(orc):
+    rng = np.random.default_rng(1)
+    b = _rand_boxes(rng, 60, spread=10.0)
+    s = rng.uniform(0, 1, 60).astype(np.float32)
+    k = orc.nms_bev(b, s, 0.01)
+    assert len(set(k)) == len(k) and np.all(np.diff(s[k]) <= 0)                 # unique, descending score
+    assert k[0] == int(np.argmax(s))
+    for a in range(len(k)):                                                      # kept boxes do not overlap above thr
+        for c in range(a + 1, len(k)):
+            assert orc.rotated_iou_bev(b[k[a]], b[k[c]]) <= 0.01
+    dropped = set(range(60)) - set(k.tolist())
+    for j in dropped:                                                            # every dropped box is covered by a better kept one
+        assert any(orc.rotated_iou_bev(b[i], b[j]) > 0.01 and (s[i], -i) > (s[j], -j) for i in k)
+    assert np.array_equal(orc.nms_bev(b, s, 1.0), np.argsort(-s, kind='stable'))   # thr = 1: nothing suppressed
+    yaw, t, cov, dims = rng.normal(size=(5, 1)), rng.normal(size=(5, 3)), rng.normal(size=(5, 4, 4)), rng.normal(size=(5, 3))
+    x = orc.score_head_inputs(yaw, t, cov, dims)
+    assert x.shape == (5, 17) and np.array_equal(x[:, 4:14], np.stack([cov[:, i, j] for i, j in
+                                                 [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 2), (3, 3)]], 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('thr', [0.01, 0.25])
+def test_gpu_nms_matches_oracle(orc, thr):
+    from monorun_amd.consumers import nms_bev
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(2)
+    groups = [_rand_boxes(rng, n, spread=sp) for n, sp in ((100, 25.0), (37, 6.0), (1, 1.0), (2, 0.5), (300, 40.0), (64, 3.0))]
+    groups.append(np.repeat(_rand_boxes(rng, 1), 5, 0))                          # identical boxes: only one survives
+    scores = [rng.uniform(0, 1, len(g)).astype(np.float32) for g in groups]
+    scores[-1][:] = 0.5                                                          # score ties -> lower index first
+    out = nms_bev([torch.from_numpy(g).to(dev) for g in groups], [torch.from_numpy(s).to(dev) for s in scores], thr)
+    torch.cuda.synchronize()
+    for g, s, k in zip(groups, scores, out):
+        ref = orc.nms_bev(g, s, thr)
+        k = k.cpu().numpy()
+        if np.array_equal(k, ref):
+            continue
+        # a difference is only acceptable at an fp32-vs-fp64 knife edge: some pair's IoU within 1e-4 of thr
+        ious = [orc.rotated_iou_bev(g[i], g[j]) for i in range(len(g)) for j in range(i + 1, len(g))]
+        assert any(abs(v - thr) < 1e-4 for v in ious), (k, ref)
+    assert out[-1].cpu().tolist() == [0]
+
+
+@pytest.mark.gpu
+def test_gpu_consumer_contracts(orc):
+    """multiclass_3d_result_nms / get_bbox_3d_result / score_head_inputs keep the reference's contracts
+    (monorun_roi_head.py:606-655, mlp_score_head.py:101-103)."""
+    from monorun_amd.consumers import multiclass_3d_result_nms, get_bbox_3d_result, score_head_inputs
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(3)
+    n = 90
+    dims = torch.from_numpy(rng.uniform(0.5, 4.0, (n, 3)).astype(np.float32)).to(dev)
+    yaw = torch.from_numpy(rng.uniform(-3, 3, (n, 1)).astype(np.float32)).to(dev)
+    t = torch.from_numpy(np.stack([rng.uniform(-20, 20, n), rng.uniform(1, 2, n), rng.uniform(5, 60, n)], 1).astype(np.float32)).to(dev)
+    scores = torch.from_numpy(rng.uniform(0, 1, n).astype(np.float32)).to(dev)
+    labels = torch.from_numpy(rng.integers(0, 3, n)).to(dev)
+    labels[labels == 2] = 0                                                       # class 2 empty, class 1 non-trivial
+    res = get_bbox_3d_result(dims, yaw, t, scores, labels, 3)
+    assert [r.shape[1] for r in res] == [8, 8, 8] and res[2].shape[0] == 0
+    out, inds = multiclass_3d_result_nms(res, 0.01, to_np=True)
+    assert isinstance(out[0], np.ndarray) and inds[2].shape == (0,) and inds[0].dtype == np.int64
+    for c in range(2):
+        r = res[c].cpu().numpy()
+        ref = orc.nms_bev(orc.xywhr2xyxyr(r[:, [3, 5, 0, 2, 6]]), r[:, 7], 0.01)
+        assert np.array_equal(inds[c], ref) and np.array_equal(out[c], r[ref])
+    out_t, inds_t = multiclass_3d_result_nms(res, 0.01, to_np=False)
+    assert torch.is_tensor(out_t[0]) and inds_t[0].dtype == torch.int64 and inds_t[2].numel() == 0
+    cov = torch.from_numpy(rng.normal(size=(n, 4, 4)).astype(np.float32)).to(dev)
+    x = score_head_inputs(yaw, t, cov, dims)
+    assert np.array_equal(x.cpu().numpy(), orc.score_head_inputs(yaw.cpu().numpy(), t.cpu().numpy(), cov.cpu().numpy(), dims.cpu().numpy()))
