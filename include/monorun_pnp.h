@@ -142,6 +142,18 @@ int mr_noc_decode_batched(
 int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int32_t *offsets, int groups, int max_group,
                        float thr, int64_t *keep, int32_t *num_keep, void *stream);
 
+/*
+ * N4: the two further entry points the reference's ext.h declares (ext.h:15-43,
+ * pnp_uncert_cpu.cpp:294-377) — exported by the reference, never called by its Python code.  Same signatures
+ * and semantics: dimpose = [log l, log h, log w, yaw, tx, ty, tz]; pts3d are NOC coordinates scaled by
+ * exp(log-dims); every residual block goes through one Huber loss (delta); wgt2d is (n,2) [wxx, wyy] for
+ * pnp_noc_uncert and (n,3) [wxx, wxy, wyy] for pnp_noc_cov_uncert.  Host fp64 buffers, one object, blocking.
+ */
+void pnp_noc_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                    double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta);
+void pnp_noc_cov_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                        double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
+    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -79,6 +79,10 @@ def load():
             vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
             vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
             vp, vp, vp, vp, vp, vp, vp]
+    for name in ('pnp_noc_uncert', 'pnp_noc_cov_uncert'):
+        f = getattr(lib, name)
+        f.restype = None
+        f.argtypes = [dp, dp, dp, dp, dp, dp, dp, ctypes.POINTER(i32), dp, i32, dp, ctypes.c_double]
     lib.mr_nms_bev_batched.restype = i32
     lib.mr_nms_bev_batched.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
     _lib = lib
@@ -93,4 +97,4 @@ def check(code):
 
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
-                    'mr_pnp_uncert_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_nms_bev_batched')
+                    'mr_pnp_uncert_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert')

@@ -51,6 +51,7 @@ struct PnpArgs {
 };
 
 #include "pnp_kernel.inc"
+#include "pnp_noc_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------
 // K2: fused NOC-head post-processing.  One thread per RoI pixel; every read of all_pred is a coalesced
@@ -519,6 +520,60 @@ void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *
     *result_tr = ho[20];
     *result_val = hv[0] ? 1 : 0;
     if (hv[0] && result_cov) memcpy(result_cov, ho.data() + 4, 16 * sizeof(double));
+}
+
+// The 7-parameter entry points of the reference's C ABI (ext.h:15-43).  Host fp64 buffers; one object; blocking.
+static void noc_host(int full_cov, double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                     double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta) {
+    *result_val = 0;
+    memcpy(result_dimpose, init_dimpose, 7 * sizeof(double));            // pnp_uncert_cpu.cpp:309,351
+    if (pn < 0) return;
+    const int ws = full_cov ? 3 : 2;
+    // device staging: [pts2d 2n | pts3d 3n | wgt ws*n | logdim 3 | logdim_wgt 3 | K 9 | init 7 | clips 5 | out 7] doubles + val int
+    const size_t n = (size_t)pn;
+    const size_t nd = (2 + 3 + ws) * n + 3 + 3 + 9 + 7 + 5 + 7;
+    const size_t bytes = nd * sizeof(double) + 16;
+    static std::mutex mu; static void *dbuf = nullptr; static size_t dcap = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes > dcap) {
+        if (dbuf) (void)hipFree(dbuf);
+        dbuf = nullptr; dcap = 0;
+        if (hipMalloc(&dbuf, bytes) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
+        dcap = bytes;
+    }
+    std::vector<double> h(nd, 0.0);
+    double *q = h.data();
+    memcpy(q, pts2d, sizeof(double) * 2 * n); q += 2 * n;
+    memcpy(q, pts3d, sizeof(double) * 3 * n); q += 3 * n;
+    memcpy(q, wgt2d, sizeof(double) * ws * n); q += ws * n;
+    memcpy(q, logdim, sizeof(double) * 3); q += 3;
+    memcpy(q, logdim_wgt, sizeof(double) * 3); q += 3;
+    memcpy(q, K, sizeof(double) * 9); q += 9;
+    memcpy(q, init_dimpose, sizeof(double) * 7); q += 7;
+    memcpy(q, clips, sizeof(double) * 5);
+    if (hipMemcpy(dbuf, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
+    double *d = (double *)dbuf;
+    NocArgs a;
+    a.pts2d = d; a.pts3d = d + 2 * n; a.wgt2d = d + 5 * n; a.logdim = d + (5 + ws) * n; a.logdim_wgt = a.logdim + 3; a.K = a.logdim + 6;
+    a.init = a.logdim + 15; a.clips = a.logdim + 22; a.out_dimpose = (double *)(a.logdim + 27); a.out_val = (int *)(d + nd);
+    a.delta = delta; a.pn = pn; a.full_cov = full_cov;
+    hipLaunchKernelGGL(pnp_noc_kernel, dim3(1), dim3(256), sizeof(double) * 2 * 4 * kRedN, nullptr, a);
+    if (hipGetLastError() != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
+    double ho[7]; int hv = 0;
+    if (hipMemcpy(ho, a.out_dimpose, sizeof ho, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&hv, a.out_val, sizeof hv, hipMemcpyDeviceToHost) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
+    memcpy(result_dimpose, ho, sizeof ho);
+    *result_val = hv;
+}
+
+void pnp_noc_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                    double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta) {
+    noc_host(0, pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, result_val, result_dimpose, pn, clips, delta);
+}
+
+void pnp_noc_cov_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                        double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta) {
+    noc_host(1, pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, result_val, result_dimpose, pn, clips, delta);
 }
 
 }  // extern "C"

@@ -365,3 +365,28 @@ def score_head_inputs(yaw, t_vec, pose_cov, dims):
     """mlp_score_head.py:101-103: [yaw, t, tril(cov) in torch.tril_indices(4,4) order, dims] -> (n, 17)."""
     r, c = np.tril_indices(4)
     return np.concatenate([yaw, t_vec, pose_cov[:, r, c], dims], axis=1)
+
+
+# ------------------------------------------------------------------ N4: the 7-parameter variants ---
+def pnp_noc(pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, clips, delta, full_cov=False):
+    """pnp_noc_uncert / pnp_noc_cov_uncert (ext.h:15-43): returns dict(val, dimpose, iters, why, ...)."""
+    pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, clips = map(_d, (pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, clips))
+    val = np.zeros(1, np.int32)
+    out = np.zeros(7)
+    diag = np.zeros(6)
+    lib().orc_noc_solve_diag(ctypes.c_int(int(full_cov)), _p(pts2d, c_dp), _p(pts3d, c_dp), _p(wgt2d, c_dp), _p(logdim, c_dp),
+                             _p(logdim_wgt, c_dp), _p(K, c_dp), _p(init_dimpose, c_dp), _p(val, c_ip), _p(out, c_dp),
+                             ctypes.c_int(pts2d.shape[0]), _p(clips, c_dp), ctypes.c_double(delta), _p(diag, c_dp))
+    return dict(val=int(val[0]), dimpose=out, iters=int(diag[0]), why=int(diag[1]), termination=int(diag[2]),
+                initial_cost=diag[3], final_cost=diag[4])
+
+
+def noc_cost_grad(pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, x, clips, delta, full_cov=False):
+    """Robustified cost 1/2 sum rho(|r_block|^2), its gradient J^T r and J^T J (corrected) at x."""
+    pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, x, clips = map(_d, (pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, x, clips))
+    cost = np.zeros(1); g = np.zeros(7); H = np.zeros((7, 7))
+    lib().orc_noc_cost_grad.restype = ctypes.c_int
+    ok = lib().orc_noc_cost_grad(ctypes.c_int(int(full_cov)), _p(pts2d, c_dp), _p(pts3d, c_dp), _p(wgt2d, c_dp), _p(logdim, c_dp),
+                                 _p(logdim_wgt, c_dp), _p(K, c_dp), _p(x, c_dp), ctypes.c_int(pts2d.shape[0]), _p(clips, c_dp),
+                                 ctypes.c_double(delta), _p(cost, c_dp), _p(g, c_dp), _p(H, c_dp))
+    return bool(ok), float(cost[0]), g, H

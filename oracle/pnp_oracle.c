@@ -40,49 +40,23 @@
 #endif
 
 /* ------------------------------------------------------------------------------------------
- * Minimal forward-mode dual number with 4 partials: the arithmetic Ceres' Jet<double,4> does.
- * (Ceres 1.14 include/ceres/jet.h — restated; formulas for *, /, sqrt, sin, cos as published.)
+ * Forward-mode dual numbers (Ceres Jet arithmetic): oracle/jet.inc instantiated for 4 partials
+ * (pose) and 7 partials (log-dims + pose, the N4 variants).
  * ---------------------------------------------------------------------------------------- */
-typedef struct { double a; double v[4]; } jet4;
-
-static jet4 j_const(double c) { jet4 r; r.a = c; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.0; return r; }
-static jet4 j_var(double c, int k) { jet4 r = j_const(c); r.v[k] = 1.0; return r; }
-static jet4 j_add(jet4 f, jet4 g) { jet4 r; r.a = f.a + g.a; for (int i = 0; i < 4; ++i) r.v[i] = f.v[i] + g.v[i]; return r; }
-static jet4 j_sub(jet4 f, jet4 g) { jet4 r; r.a = f.a - g.a; for (int i = 0; i < 4; ++i) r.v[i] = f.v[i] - g.v[i]; return r; }
-static jet4 j_mul(jet4 f, jet4 g) { jet4 r; r.a = f.a * g.a; for (int i = 0; i < 4; ++i) r.v[i] = f.a * g.v[i] + f.v[i] * g.a; return r; }
-static jet4 j_div(jet4 f, jet4 g) {
-    jet4 r; const double gi = 1.0 / g.a; const double q = f.a * gi;
-    r.a = q; for (int i = 0; i < 4; ++i) r.v[i] = (f.v[i] - q * g.v[i]) * gi; return r;
-}
-static jet4 j_sqrt(jet4 f) { jet4 r; const double t = sqrt(f.a); const double h = 1.0 / (2.0 * t); r.a = t; for (int i = 0; i < 4; ++i) r.v[i] = f.v[i] * h; return r; }
-static jet4 j_cos(jet4 f) { jet4 r; const double s = -sin(f.a); r.a = cos(f.a); for (int i = 0; i < 4; ++i) r.v[i] = s * f.v[i]; return r; }
-static jet4 j_sin(jet4 f) { jet4 r; const double c = cos(f.a); r.a = sin(f.a); for (int i = 0; i < 4; ++i) r.v[i] = c * f.v[i]; return r; }
-
-/* Ceres rotation.h AngleAxisRotatePoint, templated on T = jet4 (restated). */
-static void j_angle_axis_rotate_point(const jet4 aa[3], const jet4 pt[3], jet4 out[3]) {
-    jet4 theta2 = j_add(j_add(j_mul(aa[0], aa[0]), j_mul(aa[1], aa[1])), j_mul(aa[2], aa[2]));
-    if (theta2.a > DBL_EPSILON) {
-        jet4 theta = j_sqrt(theta2);
-        jet4 costheta = j_cos(theta);
-        jet4 sintheta = j_sin(theta);
-        jet4 theta_inv = j_div(j_const(1.0), theta);
-        jet4 w[3] = { j_mul(aa[0], theta_inv), j_mul(aa[1], theta_inv), j_mul(aa[2], theta_inv) };
-        jet4 wxp[3] = {
-            j_sub(j_mul(w[1], pt[2]), j_mul(w[2], pt[1])),
-            j_sub(j_mul(w[2], pt[0]), j_mul(w[0], pt[2])),
-            j_sub(j_mul(w[0], pt[1]), j_mul(w[1], pt[0])) };
-        jet4 tmp = j_mul(j_add(j_add(j_mul(w[0], pt[0]), j_mul(w[1], pt[1])), j_mul(w[2], pt[2])),
-                         j_sub(j_const(1.0), costheta));
-        for (int i = 0; i < 3; ++i)
-            out[i] = j_add(j_add(j_mul(pt[i], costheta), j_mul(wxp[i], sintheta)), j_mul(w[i], tmp));
-    } else {
-        jet4 wxp[3] = {
-            j_sub(j_mul(aa[1], pt[2]), j_mul(aa[2], pt[1])),
-            j_sub(j_mul(aa[2], pt[0]), j_mul(aa[0], pt[2])),
-            j_sub(j_mul(aa[0], pt[1]), j_mul(aa[1], pt[0])) };
-        for (int i = 0; i < 3; ++i) out[i] = j_add(pt[i], wxp[i]);
-    }
-}
+#define JN 4
+#define JET jet4
+#define JF(name) j_##name
+#include "jet.inc"
+#undef JN
+#undef JET
+#undef JF
+#define JN 7
+#define JET jet7
+#define JF(name) j7_##name
+#include "jet.inc"
+#undef JN
+#undef JET
+#undef JF
 
 /* ------------------------------------------------------------------------------------------
  * R1: ReprojectionErrorArray::operator() on Jets (pnp_uncert_cpu.cpp:24-51).
@@ -154,11 +128,11 @@ static int orc_eval(const orc_problem *pb, const double x[4], double *cost, doub
     return ok;
 }
 
-/* Cholesky solve of a symmetric n x n (n<=5) system, row-major full storage. 0 on non-PD.
+/* Cholesky solve of a symmetric n x n (n<=7) system, row-major full storage. 0 on non-PD.
  * Reciprocal form: one sqrt and one division per pivot, multiplications elsewhere, explicit fma —
  * the exact operation sequence is part of the K0 specification. */
 static int orc_chol_solve(int n, const double *A, const double *b, double *x) {
-    double L[25], inv[5];
+    double L[49], inv[7];
     for (int j = 0; j < n; ++j) {
         double s = A[j * n + j];
         for (int k = 0; k < j; ++k) s = fma(-L[j * n + k], L[j * n + k], s);
@@ -171,7 +145,7 @@ static int orc_chol_solve(int n, const double *A, const double *b, double *x) {
             L[i * n + j] = t * inv[j];
         }
     }
-    double y[5];
+    double y[7];
     for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s = fma(-L[i * n + k], y[k], s); y[i] = s * inv[i]; }
     for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s = fma(-L[k * n + i], x[k], s); x[i] = s * inv[i]; }
     return 1;
@@ -204,7 +178,9 @@ typedef struct {
     double initial_cost, final_cost, radius;
 } orc_lm_summary;
 
-static void orc_lm(const orc_problem *pb, const double init[4], double out[4], orc_lm_summary *sm) {
+typedef int (*orc_eval_fn)(const void *ctx, const double *x, double *cost, double *g, double *H);
+#define ORC_MAXN 7
+static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init, double *out, orc_lm_summary *sm) {
     const int    max_num_iterations = 50;
     const double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
     const double min_relative_decrease = 1e-3;
@@ -212,47 +188,47 @@ static void orc_lm(const orc_problem *pb, const double init[4], double out[4], o
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     const int    max_consecutive_invalid = 5;
 
-    double x[4]; memcpy(x, init, sizeof x); memcpy(out, init, sizeof x);
-    double cost, g[4], H[16];
+    double x[ORC_MAXN]; memcpy(x, init, sizeof(double) * n); memcpy(out, init, sizeof(double) * n);
+    double cost, g[ORC_MAXN], H[ORC_MAXN * ORC_MAXN];
     double radius = initial_radius, decrease_factor = 2.0;
     memset(sm, 0, sizeof *sm); sm->radius = radius;
 
     /* IterationZero */
-    if (!orc_eval(pb, x, &cost, g, H)) { sm->termination = ORC_FAILURE; sm->why = ORC_WHY_EVALFAIL; sm->radius = 0.0; return; }
+    if (!ev(ctx, x, &cost, g, H)) { sm->termination = ORC_FAILURE; sm->why = ORC_WHY_EVALFAIL; sm->radius = 0.0; return; }
     sm->initial_cost = sm->final_cost = cost;
-    double scale[4];
-    for (int j = 0; j < 4; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[5 * j]));   /* jacobi_scaling, from the initial J */
-    double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    double scale[ORC_MAXN];
+    for (int j = 0; j < n; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[(n + 1) * j]));   /* jacobi_scaling, from the initial J */
+    double x_norm = 0.0; for (int j = 0; j < n; ++j) x_norm += x[j] * x[j]; x_norm = sqrt(x_norm);
     int last_successful = 1;        /* iteration 0 counts as successful (IterationZero sets it) */
     int iteration = 0, invalid_run = 0;
 
     for (;;) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue (parameters are committed here) */
-        if (last_successful) { memcpy(out, x, sizeof x); sm->final_cost = cost; }
+        if (last_successful) { memcpy(out, x, sizeof(double) * n); sm->final_cost = cost; }
         sm->radius = radius; sm->num_iterations = iteration;
         if (iteration >= max_num_iterations) { sm->termination = ORC_NO_CONVERGENCE; sm->why = ORC_WHY_MAXITER; return; }
         if (last_successful) {
-            double gmax = 0.0; for (int j = 0; j < 4; ++j) if (fabs(g[j]) > gmax) gmax = fabs(g[j]);
+            double gmax = 0.0; for (int j = 0; j < n; ++j) if (fabs(g[j]) > gmax) gmax = fabs(g[j]);
             if (gmax <= gradient_tolerance) { sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_GRADIENT; return; }
         }
         if (radius <= min_radius) { sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_MINRADIUS; return; }
 
         ++iteration; last_successful = 0;
         /* ComputeTrustRegionStep — LevenbergMarquardtStrategy::ComputeStep on the scaled Jacobian */
-        double Hs[16], gs[4], A[16], D2[4], y[4], step[4];
-        for (int a = 0; a < 4; ++a) { gs[a] = g[a] * scale[a]; for (int b = 0; b < 4; ++b) Hs[4 * a + b] = H[4 * a + b] * scale[a] * scale[b]; }
-        for (int j = 0; j < 4; ++j) {
-            double d = Hs[5 * j]; d = fmin(fmax(d, min_lm_diagonal), max_lm_diagonal);
+        double Hs[ORC_MAXN * ORC_MAXN], gs[ORC_MAXN], A[ORC_MAXN * ORC_MAXN], D2[ORC_MAXN], y[ORC_MAXN], step[ORC_MAXN];
+        for (int a = 0; a < n; ++a) { gs[a] = g[a] * scale[a]; for (int b = 0; b < n; ++b) Hs[n * a + b] = H[n * a + b] * scale[a] * scale[b]; }
+        for (int j = 0; j < n; ++j) {
+            double d = Hs[(n + 1) * j]; d = fmin(fmax(d, min_lm_diagonal), max_lm_diagonal);
             D2[j] = d / radius;                       /* lm_diagonal = sqrt(diagonal/radius); D^2 enters the normal eqs */
         }
-        memcpy(A, Hs, sizeof A); for (int j = 0; j < 4; ++j) A[5 * j] += D2[j];
-        int step_ok = orc_chol_solve(4, A, gs, y);
-        if (step_ok) for (int j = 0; j < 4; ++j) { step[j] = -y[j]; if (!isfinite(step[j])) step_ok = 0; }
+        memcpy(A, Hs, sizeof(double) * n * n); for (int j = 0; j < n; ++j) A[(n + 1) * j] += D2[j];
+        int step_ok = orc_chol_solve(n, A, gs, y);
+        if (step_ok) for (int j = 0; j < n; ++j) { step[j] = -y[j]; if (!isfinite(step[j])) step_ok = 0; }
         double model_cost_change = 0.0;
         if (step_ok) {
             /* model_cost_change = -(J s)^T (r + J s / 2) = -(s^T gs + 1/2 s^T Hs s) */
             double sg = 0.0, sHs = 0.0;
-            for (int a = 0; a < 4; ++a) { sg += step[a] * gs[a]; double t = 0.0; for (int b = 0; b < 4; ++b) t += Hs[4 * a + b] * step[b]; sHs += step[a] * t; }
+            for (int a = 0; a < n; ++a) { sg += step[a] * gs[a]; double t = 0.0; for (int b = 0; b < n; ++b) t += Hs[n * a + b] * step[b]; sHs += step[a] * t; }
             model_cost_change = -(sg + 0.5 * sHs);
             step_ok = (model_cost_change > 0.0);
         }
@@ -262,12 +238,12 @@ static void orc_lm(const orc_problem *pb, const double init[4], double out[4], o
             continue;
         }
         invalid_run = 0;
-        double delta[4], cand[4];
-        for (int j = 0; j < 4; ++j) { delta[j] = step[j] * scale[j]; cand[j] = x[j] + delta[j]; }
-        double cand_cost, cg[4], cH[16];
-        if (!orc_eval(pb, cand, &cand_cost, cg, cH) ) cand_cost = DBL_MAX;   /* ComputeCandidatePointAndEvaluateCost */
+        double delta[ORC_MAXN], cand[ORC_MAXN];
+        for (int j = 0; j < n; ++j) { delta[j] = step[j] * scale[j]; cand[j] = x[j] + delta[j]; }
+        double cand_cost, cg[ORC_MAXN], cH[ORC_MAXN * ORC_MAXN];
+        if (!ev(ctx, cand, &cand_cost, cg, cH)) cand_cost = DBL_MAX;   /* ComputeCandidatePointAndEvaluateCost */
         /* ParameterToleranceReached — uses ||x - candidate|| */
-        double step_norm = 0.0; for (int j = 0; j < 4; ++j) { double d = x[j] - cand[j]; step_norm += d * d; } step_norm = sqrt(step_norm);
+        double step_norm = 0.0; for (int j = 0; j < n; ++j) { double d = x[j] - cand[j]; step_norm += d * d; } step_norm = sqrt(step_norm);
         if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) {
             sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_PARAMETER; sm->num_iterations = iteration; return; }
         /* FunctionToleranceReached */
@@ -276,8 +252,8 @@ static void orc_lm(const orc_problem *pb, const double init[4], double out[4], o
             sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_FUNCTION; sm->num_iterations = iteration; return; }
         double relative_decrease = cost_change / model_cost_change;        /* monotonic StepQuality */
         if (relative_decrease > min_relative_decrease) {                   /* HandleSuccessfulStep */
-            memcpy(x, cand, sizeof x); x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-            cost = cand_cost; memcpy(g, cg, sizeof g); memcpy(H, cH, sizeof H);
+            memcpy(x, cand, sizeof(double) * n); x_norm = 0.0; for (int j = 0; j < n; ++j) x_norm += x[j] * x[j]; x_norm = sqrt(x_norm);
+            cost = cand_cost; memcpy(g, cg, sizeof(double) * n); memcpy(H, cH, sizeof(double) * n * n);
             last_successful = 1; ++sm->num_successful;
             double t = 2.0 * relative_decrease - 1.0;                      /* StepAccepted */
             radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
@@ -287,6 +263,13 @@ static void orc_lm(const orc_problem *pb, const double init[4], double out[4], o
             radius = radius / decrease_factor; decrease_factor *= 2.0;
         }
     }
+}
+
+static int orc_eval4_cb(const void *ctx, const double *x, double *cost, double *g, double *H) {
+    return orc_eval((const orc_problem *)ctx, x, cost, g, H);
+}
+static void orc_lm(const orc_problem *pb, const double init[4], double out[4], orc_lm_summary *sm) {
+    orc_lm_n(4, orc_eval4_cb, pb, init, out, sm);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -318,6 +301,126 @@ void orc_pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, doub
                     int *result_val, double *result_pose, double *result_cov, double *result_tr,
                     int pn, double *clips) {
     orc_pnp_uncert_diag(pts2d, pts3d, wgt2d, K, init_pose, result_val, result_pose, result_cov, result_tr, pn, clips, NULL);
+}
+
+
+/* ------------------------------------------------------------------------------------------
+ * N4: the two exported-but-never-called 7-parameter variants (pnp_uncert_cpu.cpp:294-377, ext.h:15-43).
+ * dimpose = [log l, log h, log w, yaw, tx, ty, tz]; NocReprojectionErrorArray (:98-160) scales the NOC
+ * point by exp(log-dims) before the same projection / clamps; NocCovReprojectionErrorArray (:163-228)
+ * mixes the two residuals with a full 2x2 weight [wxx wxy; wxy wyy]; DimErrorArray (:77-95) is the prior
+ * on the log-dims.  EVERY residual block (the 2-vectors and the 3-vector prior) goes through ONE
+ * ceres::HuberLoss(delta) (:311,:324): restated with Ceres' Corrector (loss_function.h / corrector.cc:
+ * rho'' <= 0 for Huber => residual and Jacobian are scaled by sqrt(rho'), block cost = rho(s)/2).
+ * ---------------------------------------------------------------------------------------- */
+static void orc_noc_residual_jet(const orc_cam *c, const double dp[7], double x2d, double y2d,
+                                 double x3d, double y3d, double z3d, const double *w /*2 or 3*/, int full_cov,
+                                 double res[2], double jac[14]) {
+    jet7 p[7];
+    for (int i = 0; i < 7; ++i) p[i] = j7_var(dp[i], i);
+    jet7 pts3d[3] = { j7_mul(j7_const(x3d), j7_exp(p[0])), j7_mul(j7_const(y3d), j7_exp(p[1])), j7_mul(j7_const(z3d), j7_exp(p[2])) };
+    jet7 r_vec[3] = { j7_const(0.0), p[3], j7_const(0.0) };
+    jet7 t[3];
+    j7_angle_axis_rotate_point(r_vec, pts3d, t);
+    t[0] = j7_add(t[0], p[4]); t[1] = j7_add(t[1], p[5]); t[2] = j7_add(t[2], p[6]);
+    if (t[2].a < c->z_min) t[2] = j7_const(c->z_min);
+    jet7 proj_x = j7_add(j7_div(j7_mul(j7_const(c->fx), t[0]), t[2]), j7_const(c->cx));
+    jet7 proj_y = j7_add(j7_div(j7_mul(j7_const(c->fy), t[1]), t[2]), j7_const(c->cy));
+    if (proj_x.a < c->u_min) proj_x = j7_const(c->u_min); else if (proj_x.a > c->u_max) proj_x = j7_const(c->u_max);
+    if (proj_y.a < c->v_min) proj_y = j7_const(c->v_min); else if (proj_y.a > c->v_max) proj_y = j7_const(c->v_max);
+    jet7 dx = j7_sub(proj_x, j7_const(x2d)), dy = j7_sub(proj_y, j7_const(y2d));
+    jet7 r0, r1;
+    if (full_cov) {
+        r0 = j7_add(j7_mul(j7_const(w[0]), dx), j7_mul(j7_const(w[1]), dy));
+        r1 = j7_add(j7_mul(j7_const(w[1]), dx), j7_mul(j7_const(w[2]), dy));
+    } else {
+        r0 = j7_mul(j7_const(w[0]), dx);
+        r1 = j7_mul(j7_const(w[1]), dy);
+    }
+    res[0] = r0.a; res[1] = r1.a;
+    for (int i = 0; i < 7; ++i) { jac[i] = r0.v[i]; jac[7 + i] = r1.v[i]; }
+}
+
+/* ceres::HuberLoss::Evaluate + Corrector for one residual block of `nr` residuals (rows of J: 7 columns) */
+static double orc_huber_correct(double delta, int nr, double *r, double *J) {
+    double s = 0.0; for (int i = 0; i < nr; ++i) s += r[i] * r[i];
+    const double b = delta * delta;
+    double rho0, rho1;
+    if (s > b) { const double q = sqrt(s); rho0 = 2.0 * delta * q - b; rho1 = fmax(DBL_MIN, delta / q); }
+    else { rho0 = s; rho1 = 1.0; }
+    const double sq = sqrt(rho1);                    /* rho'' <= 0 -> alpha = 0: plain scaling (corrector.cc) */
+    for (int i = 0; i < nr; ++i) { r[i] *= sq; for (int j = 0; j < 7; ++j) J[7 * i + j] *= sq; }
+    return 0.5 * rho0;
+}
+
+typedef struct {
+    orc_cam cam; int pn, full_cov; double delta;
+    const double *pts2d, *pts3d, *wgt2d, *logdim, *logdim_wgt;
+} orc_noc_problem;
+
+static int orc_noc_eval(const void *ctx, const double *x, double *cost, double *g, double *H) {
+    const orc_noc_problem *pb = (const orc_noc_problem *)ctx;
+    double c = 0.0, gg[7], HH[49];
+    memset(gg, 0, sizeof gg); memset(HH, 0, sizeof HH);
+    const int ws = pb->full_cov ? 3 : 2;
+    for (int i = 0; i <= pb->pn; ++i) {
+        double r[3], J[21]; int nr;
+        if (i < pb->pn) {
+            nr = 2;
+            orc_noc_residual_jet(&pb->cam, x, pb->pts2d[2 * i], pb->pts2d[2 * i + 1], pb->pts3d[3 * i], pb->pts3d[3 * i + 1],
+                                 pb->pts3d[3 * i + 2], pb->wgt2d + ws * i, pb->full_cov, r, J);
+        } else {                                     /* DimErrorArray: w_k (dimpose[k] - logdim[k]) */
+            nr = 3; memset(J, 0, sizeof J);
+            for (int k = 0; k < 3; ++k) { r[k] = pb->logdim_wgt[k] * (x[k] - pb->logdim[k]); J[7 * k + k] = pb->logdim_wgt[k]; }
+        }
+        c += orc_huber_correct(pb->delta, nr, r, J);
+        for (int a = 0; a < 7; ++a) {
+            for (int q = 0; q < nr; ++q) gg[a] += J[7 * q + a] * r[q];
+            for (int b2 = 0; b2 < 7; ++b2) for (int q = 0; q < nr; ++q) HH[7 * a + b2] += J[7 * q + a] * J[7 * q + b2];
+        }
+    }
+    *cost = c;
+    int ok = isfinite(c);
+    for (int a = 0; a < 7; ++a) { g[a] = gg[a]; ok = ok && isfinite(gg[a]); }
+    for (int a = 0; a < 49; ++a) { H[a] = HH[a]; ok = ok && isfinite(HH[a]); }
+    return ok;
+}
+
+static void orc_noc_solve(int full_cov, double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt,
+                          double *K, double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips,
+                          double delta, double *diag) {
+    orc_noc_problem pb;
+    pb.cam.fx = K[0]; pb.cam.fy = K[4]; pb.cam.cx = K[2]; pb.cam.cy = K[5];
+    pb.cam.z_min = clips[0]; pb.cam.u_min = clips[1]; pb.cam.u_max = clips[2]; pb.cam.v_min = clips[3]; pb.cam.v_max = clips[4];
+    pb.pn = pn; pb.full_cov = full_cov; pb.delta = delta;
+    pb.pts2d = pts2d; pb.pts3d = pts3d; pb.wgt2d = wgt2d; pb.logdim = logdim; pb.logdim_wgt = logdim_wgt;
+    orc_lm_summary sm;
+    orc_lm_n(7, orc_noc_eval, &pb, init_dimpose, result_dimpose, &sm);
+    *result_val = (sm.termination == ORC_CONVERGENCE || sm.termination == ORC_NO_CONVERGENCE) ? 1 : 0;
+    if (diag) { diag[0] = sm.num_iterations; diag[1] = sm.why; diag[2] = sm.termination; diag[3] = sm.initial_cost; diag[4] = sm.final_cost; diag[5] = sm.num_successful; }
+}
+
+void orc_pnp_noc_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                        double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta) {
+    orc_noc_solve(0, pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, result_val, result_dimpose, pn, clips, delta, NULL);
+}
+void orc_pnp_noc_cov_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                            double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta) {
+    orc_noc_solve(1, pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, result_val, result_dimpose, pn, clips, delta, NULL);
+}
+/* test hooks: cost / gradient / J^T J of the robustified problem at x, and the solve with diagnostics */
+int orc_noc_cost_grad(int full_cov, double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                      double *x, int pn, double *clips, double delta, double *cost, double *g, double *H) {
+    orc_noc_problem pb;
+    pb.cam.fx = K[0]; pb.cam.fy = K[4]; pb.cam.cx = K[2]; pb.cam.cy = K[5];
+    pb.cam.z_min = clips[0]; pb.cam.u_min = clips[1]; pb.cam.u_max = clips[2]; pb.cam.v_min = clips[3]; pb.cam.v_max = clips[4];
+    pb.pn = pn; pb.full_cov = full_cov; pb.delta = delta;
+    pb.pts2d = pts2d; pb.pts3d = pts3d; pb.wgt2d = wgt2d; pb.logdim = logdim; pb.logdim_wgt = logdim_wgt;
+    return orc_noc_eval(&pb, x, cost, g, H);
+}
+void orc_noc_solve_diag(int full_cov, double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
+                        double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta, double *diag) {
+    orc_noc_solve(full_cov, pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, init_dimpose, result_val, result_dimpose, pn, clips, delta, diag);
 }
 
 /* ------------------------------------------------------------------------------------------
