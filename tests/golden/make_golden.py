@@ -13,6 +13,7 @@ package __init__ cannot be imported — it pulls the unbuilt cffi `_ext`, cv2, m
   core/bbox_3d/{coord,dim,proj_error}_coder/*.py ........... G3      (R10, R11, R13) via an mmcv.utils stub
   models/.../dense_decoders/fcn_noc_decoder.py::slice_pred . G3      (R9)  via mmcv/mmdet stubs
   models/.../optimizers/uncert_prop_pnp_optimizer.py ....... G4      (R8)  via mmdet stubs + a recording PnP
+  core/bbox_3d/iou_calculators/rotate_iou_kernel.py ........ G5      (N1)  rotated IoU device functions via a numba stub
 """
 import importlib.util
 import os
@@ -265,12 +266,46 @@ def make_g4(ref):
     print('G4: PnP-boundary strides seen by the reference:', a[0].stride(), a[1].stride(), a[2].stride())
 
 
+# ------------------------------------------------------------------------------- G5 ------------
+def make_g5():
+    """Rotated-rectangle IoU from the reference's own numba-CUDA device functions
+    (core/bbox_3d/iou_calculators/rotate_iou_kernel.py:11-255), executed as plain Python under a numba stub
+    (cuda.local.array -> numpy, jit decorators -> identity).  Pins the IoU restatement that the N1 NMS uses."""
+    nb = _pkg('numba')
+    cu = _pkg('numba.cuda')
+
+    def _jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    nb.jit = _jit; cu.jit = _jit; nb.cuda = cu
+    nb.float32 = np.float32; nb.int32 = np.int32
+    cu.local = types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype))
+    cu.shared = cu.local
+    _pkg('monorun.core.bbox_3d.iou_calculators')
+    rk = _load('monorun.core.bbox_3d.iou_calculators.rotate_iou_kernel', 'core/bbox_3d/iou_calculators/rotate_iou_kernel.py')
+    rng = np.random.default_rng(5)
+    n = 400
+    a = np.stack([rng.uniform(-6, 6, n), rng.uniform(-6, 6, n), rng.uniform(1.0, 5.0, n), rng.uniform(0.5, 2.5, n), rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+    b = a.copy()
+    b[:, :2] += rng.normal(0, 1.5, (n, 2)).astype(np.float32)
+    b[:, 2:4] *= rng.uniform(0.7, 1.4, (n, 2)).astype(np.float32)
+    b[:, 4] += rng.normal(0, 0.8, n).astype(np.float32)
+    b[:20] = a[:20]                                   # identical boxes
+    b[20:40, 4] = a[20:40, 4]; b[20:40, :2] = a[20:40, :2]      # concentric, same angle, different size
+    b[40:60, :2] += 30                                # disjoint
+    iou = np.array([rk.devRotateIoUEval(a[i], b[i], -1) for i in range(n)], np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g5_rotate_iou.npz'), boxes_a_xywhr=a, boxes_b_xywhr=b, iou=iou)
+    print('G5: rotated IoU pairs', n, 'mean', iou.mean().round(4), 'zeros', (iou == 0).sum(), 'ones', (np.abs(iou - 1) < 1e-6).sum())
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     ref = load_reference()
     make_g1_g2(ref)
     make_g3(ref)
     make_g4(ref)
+    make_g5()
     for f in sorted(os.listdir(OUT)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

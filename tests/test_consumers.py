@@ -108,3 +108,19 @@ def test_gpu_consumer_contracts(orc):
     cov = torch.from_numpy(rng.normal(size=(n, 4, 4)).astype(np.float32)).to(dev)
     x = score_head_inputs(yaw, t, cov, dims)
     assert np.array_equal(x.cpu().numpy(), orc.score_head_inputs(yaw.cpu().numpy(), t.cpu().numpy(), cov.cpu().numpy(), dims.cpu().numpy()))
+
+
+def test_rotated_iou_oracle_matches_reference_device_functions(orc):
+    """G5: the reference's own rotated IoU (rotate_iou_kernel.py:242-255 devRotateIoUEval, fp32, run under a
+    numba stub) on 400 box pairs — pins the restatement used to check the NMS kernel."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g5_rotate_iou.npz'))
+    a, b, ref = g['boxes_a_xywhr'].astype(np.float64), g['boxes_b_xywhr'].astype(np.float64), g['iou']
+    to_xyxyr = lambda q: np.stack([q[:, 0] - q[:, 2] / 2, q[:, 1] - q[:, 3] / 2, q[:, 0] + q[:, 2] / 2, q[:, 1] + q[:, 3] / 2, q[:, 4]], 1)
+    A, B = to_xyxyr(a), to_xyxyr(b)
+    mine = np.array([orc.rotated_iou_bev(A[i], B[i]) for i in range(len(A))])
+    assert (ref[40:60] == 0).all()
+    # pairs 0..19 are IDENTICAL boxes: the reference's intersection-point logic is ill-defined on exactly
+    # coincident edges (it returns 1/3 or 0 there, not 1) — a degeneracy of that kernel, not a target to match
+    assert np.abs(mine[:20] - 1).max() < 1e-12 and (ref[:20] < 0.99).sum() >= 15
+    assert np.abs(mine[20:] - ref[20:]).max() < 2e-5, np.abs(mine[20:] - ref[20:]).max()      # the reference computes in float32
