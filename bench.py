@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary (multi-stream / 8192-object) throughput figures')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample time')
     ap.add_argument('--waves', type=int, default=0, help='wavefronts per object (0 = library heuristic)')
     return ap.parse_args()
@@ -166,7 +167,7 @@ def main():
     #      would): at B = 1024 a launch lasts as long as its slowest object, streams fill the idle SIMDs of the tail;
     #  (b) one launch over 8 such batches (8192 objects): the kernel's throughput regime.
     extra = {}
-    if world == 1:
+    if world == 1 and not args.no_secondary:
         n_str = 4
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
         launches = [PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr,
@@ -209,6 +210,17 @@ def main():
                 traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
             except Exception:  # noqa: BLE001
                 traffic = None
+        valu = None
+        sfile = os.path.join(ROOT, 'profiles', 'r01_summary.json')       # PMC instruction counts of the same command
+        if os.path.exists(sfile):
+            try:
+                cnt = json.load(open(sfile))['counters']['SQ_INSTS_VALU']['mean']
+                # every VALU wave-instruction occupies its SIMD for >= 2 (fp32) .. 4 (fp64) cycles; 1024 SIMDs at 2.4 GHz
+                t_min = cnt * 4.0 / (1024 * 2.4e9)
+                valu = {'valu_insts_per_launch': cnt, 'min_issue_time_us_at_4_cycles': t_min * 1e6,
+                        'frac_of_kernel_time': t_min / (kernel_ms * 1e-3)}
+            except Exception:  # noqa: BLE001
+                valu = None
         line = {
             'metric': 'PnP solves/sec (1024 proposals, 28x28 corr.)', 'value': total / elapsed, 'unit': 'solves/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -220,7 +232,7 @@ def main():
                        'parallelism': f'objects sharded x{world}' + (', 1 RCCL all-gather of 88 B/object per step' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
-                         'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU,
+                         'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU, 'valu_issue': valu,
                          'note': 'formally HBM-bound (read-once streaming); in practice VALU/latency-bound: the tile is LDS-resident '
                                  'across all LM iterations (DESIGN.md)'},
             'valid_fraction': valid_frac,
