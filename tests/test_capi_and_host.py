@@ -102,3 +102,28 @@ def test_synthetic_generator_shapes_and_determinism():
     assert x2d.strides == (1568 * 4, 4, 784 * 4) and x3d.strides == (2352 * 4, 4, 784 * 4)
     assert np.array_equal(ur, [[-200, 1442]]) and np.array_equal(vr, [[-200, 575]])
     np.testing.assert_allclose(thr, 0.2 * 27 / 28 * (a['rois'][:, 3] - a['rois'][:, 1]), rtol=1e-4)
+
+
+def test_capi_argument_validation_without_a_gpu():
+    """Bad arguments are rejected before any HIP call, so this runs on CPU: error codes of include/monorun_pnp.h."""
+    from monorun_amd import _lib
+    lib = _lib.load()
+    st = (ctypes.c_int64 * 3)(1568, 1, 784)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+
+    def call(B=4, P=784, x2d=p, cam_batch=1, range_batch=1, cov=p, dtype=0, flags=0):
+        return lib.mr_pnp_uncert_batched(x2d, st, p, st, p, st, dtype, p, cam_batch, p, p, range_batch, None, None, B, P,
+                                         0.5, 0.6, 1, flags, p, p, cov, p, p, None, None)
+    assert call(B=0) == 0                                     # empty batch: success, nothing launched
+    assert call(B=-1) == -1 and call(P=3) == -1 and call(P=10 ** 6) == -1
+    assert call(x2d=None) == -1 and call(cov=None) == -1
+    assert call(cov=None, flags=_lib.MR_COV_NONE, B=0) == 0
+    assert call(cam_batch=3) == -1 and call(range_batch=2) == -1
+    assert call(P=8192) == -2                                 # tile does not fit the 160 KB LDS
+    assert call(dtype=7) == -2
+    assert lib.mr_pnp_error_string(-2).startswith(b'unsupported') and lib.mr_pnp_error_string(-99) == b'unknown error'
+    # NMS / decode entry points validate too
+    assert lib.mr_nms_bev_batched(None, None, None, 0, 0, 0.1, None, None, None) == 0
+    assert lib.mr_nms_bev_batched(p, p, p, 1, 4096, 0.1, p, p, None) == -2
+    assert lib.mr_nms_bev_batched(p, p, None, 1, 8, 0.1, p, p, None) == -1

@@ -295,3 +295,67 @@ def test_bench_workload_matches_oracle_object_by_object(dev, orc, seed, B):
     x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
     ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
     _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, thr), ref, f'seed={seed} B={B}')
+
+
+def test_side_stream_misaligned_and_strided_inputs(dev, orc, batch64):
+    """(a) launch on a non-default stream (asynchronous, results valid after that stream syncs);
+    (b) planar input whose base is only 4-byte aligned -> the dword LDS-DMA path;
+    (c) non-contiguous object blocks (every second point of a larger tensor) -> the gather path;
+    (d) fp16 planar input with odd byte counts -> the element-wise copy path."""
+    from monorun_amd.ops.least_squares.pnp_uncert import PnPLaunch
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=True)
+    n = 32
+    ref = orc.u2d_pnp(x2d[:n], istd[:n], x3d[:n], K, ur, vr, 0.5, 0.6, thr[:n], True, return_diag=True)
+    t = lambda a: _dv(a, dev)
+    # (a) side stream
+    s = torch.cuda.Stream(device=dev)
+    L = PnPLaunch(t(x2d[:n]), t(istd[:n]), t(x3d[:n]), t(K), t(ur), t(vr), 0.5, 0.6, t(thr[:n]), True, with_diag=True)
+    L.run(s.cuda_stream)
+    s.synchronize()
+    _cmp((L.valid.cpu().numpy().astype(bool), L.pose.cpu().numpy(), L.cov.cpu().numpy(), L.tr.cpu().numpy(),
+          L.mask.cpu().numpy().astype(bool), L.diag.cpu().numpy()), ref, 'side stream')
+
+    # (b) 4-byte aligned base: allocate one extra float in front and view from element 1
+    def shifted(a):
+        flat = torch.empty(a.size + 1, dtype=torch.float32, device=dev)
+        base = np.ascontiguousarray(np.asarray(a).transpose(0, 2, 1))            # (n, C, P) contiguous = planar memory image
+        flat[1:] = torch.from_numpy(base.reshape(-1)).to(dev)
+        nb, C, P = base.shape
+        return torch.as_strided(flat, (nb, P, C), (C * P, 1, P), storage_offset=1)
+    xs, ws_, x3s = shifted(x2d[:n]), shifted(istd[:n]), shifted(x3d[:n])
+    assert xs.data_ptr() % 16 == 4
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    out = pnp_uncert_device(xs, ws_, x3s, t(K), t(ur), t(vr), 0.5, 0.6, t(thr[:n]), True, with_diag=True)
+    torch.cuda.synchronize()
+    o = [v.cpu().numpy() for v in out]
+    _cmp((o[0].astype(bool), o[1], o[2], o[3], o[4].astype(bool), o[5]), ref, 'misaligned planar')
+
+    # (c) every second point of a (n, 2P, C) contiguous tensor: object blocks are not contiguous
+    def interleave(a):
+        a = np.ascontiguousarray(a)
+        big = np.zeros((a.shape[0], 2 * a.shape[1], a.shape[2]), np.float32)
+        big[:, ::2] = a
+        return t(big)[:, ::2]
+    xi, wi, x3i = interleave(x2d[:n]), interleave(istd[:n]), interleave(x3d[:n])
+    assert not xi.is_contiguous()
+    refc = orc.u2d_pnp(np.ascontiguousarray(x2d[:n]), np.ascontiguousarray(istd[:n]), np.ascontiguousarray(x3d[:n]), K, ur, vr,
+                       0.5, 0.6, thr[:n], True, return_diag=True)                 # stride_p != 1 -> numpy's sequential mean order
+    out = pnp_uncert_device(xi, wi, x3i, t(K), t(ur), t(vr), 0.5, 0.6, t(thr[:n]), True, with_diag=True)
+    torch.cuda.synchronize()
+    o = [v.cpu().numpy() for v in out]
+    _cmp((o[0].astype(bool), o[1], o[2], o[3], o[4].astype(bool), o[5]), refc, 'strided gather')
+
+    # (d) fp16, P = 101 (C*P*2 bytes not a multiple of 4 for C = 3)
+    rng = np.random.default_rng(9)
+    P = 101
+    c = syn.cube_config1(n_points=P * 8, seed=4)
+    h2 = (c['pts2d'] + rng.normal(0, 0.5, c['pts2d'].shape)).reshape(8, P, 2).astype(np.float16)
+    h3 = c['pts3d'].reshape(8, P, 3).astype(np.float16)
+    hw = (np.exp(-rng.normal(np.log(2.0), 0.5, (8, P, 2))) / 10).astype(np.float16)
+    pl = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1)).transpose(0, 2, 1)
+    h2, h3, hw = pl(h2), pl(h3), pl(hw)
+    Kc = c['K'][None].astype(np.float32)
+    thr8 = np.full(8, 6.0, np.float32)
+    ref16 = orc.u2d_pnp(pl(h2.astype(np.float32)), pl(hw.astype(np.float32)), pl(h3.astype(np.float32)), Kc, ur, vr, 0.5, 0.6, thr8, True,
+                        return_diag=True)
+    _cmp(_run(dev, h2, hw, h3, Kc, ur, vr, thr8), ref16, 'fp16 odd sizes')
