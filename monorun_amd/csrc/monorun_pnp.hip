@@ -350,8 +350,10 @@ int pick_wpo(int B, int P, int flags) {
     // wave issues only ~1 VALU instruction per 7 cycles, so small batches are split over more wavefronts per
     // object (measured on MI355X: B = 1024 is fastest at 4 waves/object, B = 8192 at 2).
     w = 1;
-    while (w < 4 && (long long)B * w * 2 <= 4096 && P >= 64 * w * 2) w *= 2;
-    if (w == 1 && P >= 256) w = 2;
+    while (w < 4 && (long long)B * w * 2 <= 4096 && P >= 64 * w * 2) w *= 2;      // small batches: fill the SIMDs
+    int wp = 1;
+    while (wp < 4 && P > 64 * wp * 8) wp *= 2;                                     // large tiles: <= ~8 points per lane
+    if (wp > w) w = wp;                                                            // (P = 784 -> 2, P = 3136 -> 4)
     return w;
 }
 
