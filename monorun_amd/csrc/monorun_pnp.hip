@@ -6,6 +6,7 @@
 #include <string.h>
 #include <mutex>
 #include <vector>
+#include <type_traits>
 
 #include "monorun_pnp.h"
 
