@@ -130,6 +130,25 @@ int mr_noc_decode_batched(
     void *stream);
 
 /*
+ * Fused K2 + PnP: from the raw NOC-head output to the pose in ONE launch — the decoded maps are built
+ * directly in the kernel's LDS tile and never touch HBM.  Arguments = those of mr_noc_decode_batched (head
+ * output, constants) followed by those of mr_pnp_uncert_batched (camera, ranges, options, outputs); results
+ * are identical, bit for bit, to calling the two entry points in sequence.  dims / dims_var (B,3): optional
+ * decoded dimensions for the consumers.  ransac_thres_ratio < 0 disables the consensus step.
+ */
+int mr_pnp_from_head_batched(
+    const float *all_pred, const int64_t *labels, const uint8_t *flip,
+    const float *dim, const float *dim_var, const float *rois,
+    int B, int num_classes, int class_agnostic, int h, int w,
+    const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
+    double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain,
+    float std_scale, float ransac_thres_ratio,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    float z_min, float istd_thres, int inlier_opt_only, int flags,
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
+    float *dims, float *dims_var, void *stream);
+
+/*
  * N1: rotated-BEV NMS of the pose consumers — replaces mmdet3d.ops.iou3d.nms_gpu as called by
  * multiclass_3d_result_nms (monorun/models/roi_heads/monorun_roi_head.py:619-655).
  *   boxes_xyxyr (total,5) f32 [x1, y1, x2, y2, ry] (xywhr2xyxyr, :657-677), scores (total) f32,

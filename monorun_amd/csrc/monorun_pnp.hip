@@ -21,6 +21,97 @@ constexpr int kRedN = 32;           // doubles per wave in the cross-wave reduct
 #define MR_MIN_WAVES 3              // waves per SIMD the register allocator must allow (<= 168 VGPRs, no spills)
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// K2: fused NOC-head post-processing.  One thread per RoI pixel; every read of all_pred is a coalesced
+// row of the selected channel, every write a coalesced row of a channel-planar output map.
+//   R9  flip/class channel pick   fcn_noc_decoder.py:225-267  (integer indexing, bit-exact)
+//   R10 dim + NOC decode          multiclass_norm_dim_coder.py:28-36, noc_coder.py:50-73
+//   R11 log-std decode            distance_invar_proj_error_coder.py:39-60 (distance=None)
+//   R8  istd, RANSAC threshold    uncert_prop_pnp_optimizer.py:73,86-88
+//   R12 RoI bin-centre grid       roi_align(coord_2d, ..., 'avg', aligned=True), interior analytic form
+// fp32 with unfused multiply-adds, i.e. the rounding sequence of the reference's elementwise torch ops.
+// The per-object / per-pixel arithmetic is shared with the fused path of the PnP kernel (decoded maps
+// written straight into its LDS tile, never to HBM).
+struct DecodeArgs {
+    const float *all_pred; const long long *labels; const uint8_t *flip; const float *dim, *dim_var, *rois;
+    int B, C, agnostic, h, w;
+    const float *dim_means, *dim_stds; float noc_mean[3], noc_std[3];
+    float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
+    float *c2d, *istd, *c3d, *dims, *dims_var, *thr;
+};
+
+struct DecodeObj { float dm[3], dv[3]; float x1, y1, su, sv, thr; const float *base; int ch_noc, ch_ls; };
+
+__device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, DecodeObj &o) {
+#pragma clang fp contract(off)
+    const int hw = a.h * a.w;
+    const int lab = (int)a.labels[b];
+    const int c = a.agnostic ? 0 : lab;
+    const int f = a.flip[b] ? 1 : 0;
+    const int Cn = a.agnostic ? 1 : a.C;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float sd = a.dim_stds[lab * 3 + k];
+        o.dm[k] = a.dim[b * 3 + k] * sd + a.dim_means[lab * 3 + k];
+        o.dv[k] = a.has_var ? a.dim_var[b * 3 + k] * (sd * sd) : 0.0f;
+    }
+    const float x1 = a.rois[b * 4 + 0], y1 = a.rois[b * 4 + 1], x2 = a.rois[b * 4 + 2], y2 = a.rois[b * 4 + 3];
+    o.x1 = x1; o.y1 = y1;
+    o.su = (x2 - x1) / (float)a.w; o.sv = (y2 - y1) / (float)a.h;
+    const float v_last = (y1 - 0.5f) + ((float)(a.h - 1) + 0.5f) * o.sv, v_first = (y1 - 0.5f) + 0.5f * o.sv;
+    o.thr = a.ratio * (v_last - v_first);
+    o.base = a.all_pred + (long long)b * (2 * Cn * 5) * hw;
+    o.ch_noc = f * 5 * Cn + 3 * c; o.ch_ls = f * 5 * Cn + 3 * Cn + 2 * c;
+}
+
+__device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeObj &o, int p, float (&c2d)[2], float (&istd)[2], float (&c3d)[3]) {
+#pragma clang fp contract(off)
+    const int hw = a.h * a.w;
+    const int py = p / a.w, px = p - py * a.w;
+    float xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float noc = o.base[(long long)(o.ch_noc + k) * hw + p];
+        const float part = noc * a.noc_std[k] + a.noc_mean[k];
+        c3d[k] = part * o.dm[k];
+        xv[k] = o.dv[k] * (part * part);
+    }
+    const float v2[2] = { 0.5f * (xv[0] + xv[2]), xv[1] };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float ls = o.base[(long long)(o.ch_ls + k) * hw + p];
+        float lspx;
+        if (a.has_var) lspx = 0.5f * logf((v2[k] * a.k_epi + expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
+        else lspx = ls + 0.0f;                                    // log(sd / sd)
+        istd[k] = expf(-lspx) / a.std_scale;
+    }
+    c2d[0] = (o.x1 - 0.5f) + ((float)px + 0.5f) * o.su;
+    c2d[1] = (o.y1 - 0.5f) + ((float)py + 0.5f) * o.sv;
+}
+
+__global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
+    const int b = blockIdx.y;
+    const int hw = a.h * a.w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    DecodeObj o;
+    decode_object(a, b, o);
+    if (p == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (a.dims) a.dims[b * 3 + k] = o.dm[k];
+            if (a.dims_var && a.has_var) a.dims_var[b * 3 + k] = o.dv[k];
+        }
+        if (a.thr) a.thr[b] = o.thr;
+    }
+    if (p >= hw) return;
+    float c2d[2], istd[2], c3d[3];
+    decode_pixel(a, o, p, c2d, istd, c3d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.c3d[((long long)b * 3 + k) * hw + p] = c3d[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { a.istd[((long long)b * 2 + k) * hw + p] = istd[k]; a.c2d[((long long)b * 2 + k) * hw + p] = c2d[k]; }
+}
+
 // numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host:
 // leaves (blocks of <=128 elements) + the combine tree, internal nodes ordered by height so that the
 // kernel can evaluate it level by level.  Value slots: [0, n_leaves) leaves, n_leaves + k internal k.
@@ -47,84 +138,14 @@ struct PnpArgs {
     double z_min; float istd_thres; int inlier_opt_only; int flags; int mean_mode;
     uint8_t *valid; float *pose; float *cov; float *tr; uint8_t *mask; float *diag;
     double *pose64, *cov64, *tr64;            // legacy per-object ABI outputs (nullable)
-    unsigned long long *stamps;               // debug: (B,10) s_memtime stamps per stage + HW_ID + XCC_ID (nullable)
+    unsigned long long *stamps;               // debug: (B,24) s_memtime stamps (nullable)
+    int from_head;                            // 1: the tile is decoded in-kernel from the raw NOC-head output (`dec`)
+    DecodeArgs dec;
     PairwisePlan plan;
 };
 
 #include "pnp_kernel.inc"
 #include "pnp_noc_kernel.inc"
-
-// ------------------------------------------------------------------------------------------------
-// K2: fused NOC-head post-processing.  One thread per RoI pixel; every read of all_pred is a coalesced
-// row of the selected channel, every write a coalesced row of a channel-planar output map.
-//   R9  flip/class channel pick   fcn_noc_decoder.py:225-267  (integer indexing, bit-exact)
-//   R10 dim + NOC decode          multiclass_norm_dim_coder.py:28-36, noc_coder.py:50-73
-//   R11 log-std decode            distance_invar_proj_error_coder.py:39-60 (distance=None)
-//   R8  istd, RANSAC threshold    uncert_prop_pnp_optimizer.py:73,86-88
-//   R12 RoI bin-centre grid       roi_align(coord_2d, ..., 'avg', aligned=True), interior analytic form
-// fp32 with unfused multiply-adds, i.e. the rounding sequence of the reference's elementwise torch ops.
-struct DecodeArgs {
-    const float *all_pred; const long long *labels; const uint8_t *flip; const float *dim, *dim_var, *rois;
-    int B, C, agnostic, h, w;
-    const float *dim_means, *dim_stds; float noc_mean[3], noc_std[3];
-    float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
-    float *c2d, *istd, *c3d, *dims, *dims_var, *thr;
-};
-
-__global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
-#pragma clang fp contract(off)
-    const int b = blockIdx.y;
-    const int hw = a.h * a.w;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int lab = (int)a.labels[b];
-    const int c = a.agnostic ? 0 : lab;
-    const int f = a.flip[b] ? 1 : 0;
-    const int Cn = a.agnostic ? 1 : a.C;
-    float dm[3], dv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float sd = a.dim_stds[lab * 3 + k];
-        dm[k] = a.dim[b * 3 + k] * sd + a.dim_means[lab * 3 + k];
-        dv[k] = a.has_var ? a.dim_var[b * 3 + k] * (sd * sd) : 0.0f;
-    }
-    const float x1 = a.rois[b * 4 + 0], y1 = a.rois[b * 4 + 1], x2 = a.rois[b * 4 + 2], y2 = a.rois[b * 4 + 3];
-    const float su = (x2 - x1) / (float)a.w, sv = (y2 - y1) / (float)a.h;
-    if (p == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (a.dims) a.dims[b * 3 + k] = dm[k];
-            if (a.dims_var && a.has_var) a.dims_var[b * 3 + k] = dv[k];
-        }
-        if (a.thr) {
-            const float v_last = (y1 - 0.5f) + ((float)(a.h - 1) + 0.5f) * sv, v_first = (y1 - 0.5f) + 0.5f * sv;
-            a.thr[b] = a.ratio * (v_last - v_first);
-        }
-    }
-    if (p >= hw) return;
-    const int py = p / a.w, px = p - py * a.w;
-    const float *base = a.all_pred + (long long)b * (2 * Cn * 5) * hw;
-    const int ch_noc = f * 5 * Cn + 3 * c, ch_ls = f * 5 * Cn + 3 * Cn + 2 * c;
-    float xv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float noc = base[(long long)(ch_noc + k) * hw + p];
-        const float part = noc * a.noc_std[k] + a.noc_mean[k];
-        a.c3d[((long long)b * 3 + k) * hw + p] = part * dm[k];
-        xv[k] = dv[k] * (part * part);
-    }
-    const float v2[2] = { 0.5f * (xv[0] + xv[2]), xv[1] };
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float ls = base[(long long)(ch_ls + k) * hw + p];
-        float lspx;
-        if (a.has_var) lspx = 0.5f * logf((v2[k] * a.k_epi + expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
-        else lspx = ls + 0.0f;                                    // log(sd / sd)
-        a.istd[((long long)b * 2 + k) * hw + p] = expf(-lspx) / a.std_scale;
-    }
-    a.c2d[((long long)b * 2 + 0) * hw + p] = (x1 - 0.5f) + ((float)px + 0.5f) * su;
-    a.c2d[((long long)b * 2 + 1) * hw + p] = (y1 - 0.5f) + ((float)py + 0.5f) * sv;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // N1: rotated-BEV NMS, the consumer that follows the PnP (monorun_roi_head.py:619-655 calls
@@ -426,17 +447,13 @@ int mr_pnp_uncert_batched(
     }
 }
 
-int mr_noc_decode_batched(
-    const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
-    int B, int num_classes, int class_agnostic, int h, int w,
-    const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
-    double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
-    float *coords_2d, float *coords_2d_istd, float *coords_3d, float *dims, float *dims_var, float *ransac_thr, void *stream) {
-    if (B < 0 || h < 1 || w < 1 || num_classes < 1 || B > 65535) return MR_ERR_BAD_ARGUMENT;
-    if (B == 0) return MR_OK;
-    if (!all_pred || !labels || !flip || !dim || !rois || !dim_means || !dim_stds || !noc_means || !noc_stds ||
-        !coords_2d || !coords_2d_istd || !coords_3d) return MR_ERR_BAD_ARGUMENT;
-    DecodeArgs a;
+static int fill_decode_args(DecodeArgs &a, const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim,
+                            const float *dim_var, const float *rois, int B, int num_classes, int class_agnostic, int h, int w,
+                            const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
+                            double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale,
+                            float ransac_thres_ratio) {
+    if (B < 0 || h < 1 || w < 1 || num_classes < 1) return MR_ERR_BAD_ARGUMENT;
+    if (!all_pred || !labels || !flip || !dim || !rois || !dim_means || !dim_stds || !noc_means || !noc_stds) return MR_ERR_BAD_ARGUMENT;
     memset(&a, 0, sizeof a);
     a.all_pred = all_pred; a.labels = (const long long *)labels; a.flip = flip; a.dim = dim; a.dim_var = dim_var; a.rois = rois;
     a.B = B; a.C = num_classes; a.agnostic = class_agnostic; a.h = h; a.w = w;
@@ -449,12 +466,65 @@ int mr_noc_decode_batched(
     const float sdf = (float)proj_scaling_denominator;
     a.sd_sq = sdf * sdf;
     a.std_scale = std_scale; a.ratio = ransac_thres_ratio; a.has_var = dim_var != nullptr;
+    return MR_OK;
+}
+
+int mr_noc_decode_batched(
+    const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
+    int B, int num_classes, int class_agnostic, int h, int w,
+    const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
+    double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
+    float *coords_2d, float *coords_2d_istd, float *coords_3d, float *dims, float *dims_var, float *ransac_thr, void *stream) {
+    if (B == 0) return MR_OK;
+    if (B > 65535) return MR_ERR_BAD_ARGUMENT;
+    DecodeArgs a;
+    const int rc = fill_decode_args(a, all_pred, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
+                                    noc_means, noc_stds, proj_scaling_denominator, ref_focal_y, epistemic_std_gain, std_scale, ransac_thres_ratio);
+    if (rc != MR_OK) return rc;
+    if (!coords_2d || !coords_2d_istd || !coords_3d) return MR_ERR_BAD_ARGUMENT;
     a.c2d = coords_2d; a.istd = coords_2d_istd; a.c3d = coords_3d; a.dims = dims; a.dims_var = dims_var;
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     const int hw = h * w;
     hipLaunchKernelGGL(noc_decode_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return MR_OK;
+}
+
+int mr_pnp_from_head_batched(
+    const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
+    int B, int num_classes, int class_agnostic, int h, int w,
+    const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
+    double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    float z_min, float istd_thres, int inlier_opt_only, int flags,
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
+    float *dims, float *dims_var, void *stream) {
+    const int P = h * w;
+    if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!cam_mats || !u_range || !v_range || !valid || !pose || !tr_radius || (!cov && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
+    if ((cam_batch != 1 && cam_batch != B) || (range_batch != 1 && range_batch != B)) return MR_ERR_BAD_ARGUMENT;
+    PnpArgs a;
+    memset(&a, 0, sizeof a);
+    const int rc = fill_decode_args(a.dec, all_pred, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
+                                    noc_means, noc_stds, proj_scaling_denominator, ref_focal_y, epistemic_std_gain, std_scale, ransac_thres_ratio);
+    if (rc != MR_OK) return rc;
+    a.dec.dims = dims; a.dec.dims_var = dims_var;
+    a.from_head = 1;
+    // the tile is built channel-planar, exactly the layout (and hence numpy summation order) the reference's head produces
+    a.s2[0] = 2LL * P; a.s2[1] = 1; a.s2[2] = P; a.sw[0] = 2LL * P; a.sw[1] = 1; a.sw[2] = P; a.s3[0] = 3LL * P; a.s3[1] = 1; a.s3[2] = P;
+    a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
+    a.ur = u_range; a.vr = v_range; a.r_stride = (range_batch == 1) ? 0 : 2; a.r_f64 = 0;
+    a.B = B; a.P = P; a.z_min = (double)z_min; a.istd_thres = istd_thres; a.inlier_opt_only = inlier_opt_only; a.flags = flags;
+    a.valid = valid; a.pose = pose; a.cov = cov; a.tr = tr_radius; a.mask = inlier_mask; a.diag = diag;
+    a.stamps = g_stamps;
+    int mm = flags & MR_MEAN_MASK;
+    if (mm == MR_MEAN_AUTO) mm = MR_MEAN_PAIRWISE;
+    a.mean_mode = mm;
+    if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
+        if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
+    }
+    return launch_wpo<float>(a, pick_wpo(B, P, flags), (hipStream_t)stream);
 }
 
 int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int32_t *offsets, int groups, int max_group,

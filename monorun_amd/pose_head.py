@@ -9,7 +9,8 @@
     (losses are training-only and out of scope: SURVEY.md §8)
   * ``cov_correction`` — R13 (distance_invar_proj_error_coder.py:62-63 with the 'range' distance of
     uncert_projection_head.py:104-109), applied at monorun_roi_head.py:530-534
-  * ``pose_from_head`` — the whole post-NOC-head tail in two launches (K2 -> fused PnP)
+  * ``pnp_from_head`` / ``pose_from_head`` — the whole post-NOC-head tail in ONE launch (K2 fused into the PnP kernel's
+    load stage; the decoded maps never touch HBM), or two launches with ``fused=False``
 """
 import torch
 import torch.nn as nn
@@ -73,6 +74,60 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
                 dims_var.data_ptr() if dims_var is not None else None, thr.data_ptr() if thr is not None else None,
                 torch.cuda.current_stream(dev).cuda_stream))
     return dict(coords_2d=c2d, coords_2d_istd=istd, coords_3d=c3d, dims=dims, dims_var=dims_var, ransac_thr=thr)
+
+
+def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shapes, num_classes=3, class_agnostic=False,
+                  dim_means=DIM_MEANS, dim_stds=DIM_STDS, noc_means=NOC_MEANS, noc_stds=NOC_STDS,
+                  ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0, std_scale=10,
+                  epnp_ransac_thres_ratio=0.2, allowed_border=200, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True,
+                  flags=0, with_diag=False):
+    """Raw NOC-head output -> (ret_val, yaw, t_vec, pose_cov, inlier_mask, dims, dims_var[, diag]) in ONE launch
+    (``mr_pnp_from_head_batched``): the decoded 2D/3D/istd maps only ever exist in the kernel's LDS tile."""
+    lib = _lib.load()
+    dev = all_pred.device
+    if dev.type != 'cuda':
+        raise RuntimeError('monorun_amd.pnp_from_head runs on an MI355X only (no CPU fallback)')
+    B, ch, h, w = all_pred.shape
+    Cn = 1 if class_agnostic else num_classes
+    assert ch == 2 * Cn * 5, f'all_pred has {ch} channels, expected {2 * Cn * 5}'
+    f32 = dict(device=dev, dtype=torch.float32)
+    ap = all_pred.detach().to(**f32).contiguous()
+    lab = labels.detach().to(device=dev, dtype=torch.int64).contiguous()
+    fl = torch.full((B,), int(flip), device=dev, dtype=torch.uint8) if isinstance(flip, bool) \
+        else torch.as_tensor(flip, device=dev).to(torch.uint8).contiguous()
+    dm = dim.detach().to(**f32).contiguous()
+    dv = dim_var.detach().to(**f32).contiguous() if dim_var is not None else None
+    r = rois.detach().to(**f32)
+    r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
+    t = lambda v: torch.tensor(v, **f32).contiguous()
+    mu, sd, nm, ns = t(dim_means), t(dim_stds), t(noc_means), t(noc_stds)
+    cam = cam_intrinsic.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    img_shapes = torch.as_tensor(img_shapes, device=dev, dtype=torch.float32).reshape(-1, 2)
+    ur = torch.full((img_shapes.size(0), 2), -float(allowed_border), **f32)
+    vr = torch.full((img_shapes.size(0), 2), -float(allowed_border), **f32)
+    ur[:, 1] = img_shapes[:, 1] + allowed_border
+    vr[:, 1] = img_shapes[:, 0] + allowed_border
+    P = h * w
+    valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    pose = torch.empty(B, 4, **f32); cov = torch.empty(B, 4, 4, **f32); tr = torch.empty(B, **f32)
+    mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    diag = torch.empty(B, 4, **f32) if with_diag else None
+    dims = torch.empty(B, 3, **f32)
+    dims_var = torch.empty(B, 3, **f32) if dv is not None else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_pnp_from_head_batched(
+                ap.data_ptr(), lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
+                B, num_classes, int(class_agnostic), h, w, mu.data_ptr(), sd.data_ptr(), nm.data_ptr(), ns.data_ptr(),
+                float(ref_length * ref_focal_y * target_std), float(ref_focal_y), float(epistemic_std_gain), float(std_scale),
+                float(epnp_ransac_thres_ratio) if epnp_ransac_thres_ratio is not None else -1.0,
+                cam.data_ptr(), cam.shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                float(z_min), float(epnp_istd_thres), int(bool(inlier_opt_only)), int(flags),
+                valid.data_ptr(), pose.data_ptr(), cov.data_ptr(), tr.data_ptr(), mask.data_ptr(),
+                diag.data_ptr() if diag is not None else None, dims.data_ptr(),
+                dims_var.data_ptr() if dims_var is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+    out = (valid.bool(), pose[:, :1], pose[:, 1:], cov, mask.bool(), dims, dims_var)
+    return out + (diag,) if with_diag else out
 
 
 def _planar_view(x):
@@ -149,14 +204,25 @@ class UncertPropPnPOptimizer(nn.Module):
 
 
 def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape,
-                   apply_cov_correction=True, **decode_kw):
-    """NOC-head output -> pose results dict (what monorun_roi_head.py:509-534 produces), two launches."""
-    dec = noc_decode(all_pred, labels, flip, dim, dim_var, rois, std_scale=pose_head.std_scale,
-                     epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, **decode_kw)
-    img_shapes = torch.as_tensor(img_shape, device=all_pred.device, dtype=torch.float32).reshape(-1, 2)
-    ret_val, yaw, t_vec, cov, cov_calib = pose_head.forward_decoded(dec, cam_intrinsic, img_shapes)
+                   apply_cov_correction=True, fused=True, **decode_kw):
+    """NOC-head output -> pose results dict (what monorun_roi_head.py:509-534 produces).
+    fused=True: ONE launch (decode inside the PnP kernel); fused=False: K2 then the PnP kernel (two launches,
+    the decoded maps are materialised) — both give bit-identical results."""
+    if fused:
+        p = pose_head.pnp
+        ret_val, yaw, t_vec, cov, _, dims, dims_var = pnp_from_head(
+            all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape, std_scale=pose_head.std_scale,
+            epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, allowed_border=pose_head.allowed_border,
+            z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, inlier_opt_only=p.inlier_opt_only, **decode_kw)
+        cov_calib = pose_head._calibrate(cov)
+    else:
+        dec = noc_decode(all_pred, labels, flip, dim, dim_var, rois, std_scale=pose_head.std_scale,
+                         epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, **decode_kw)
+        img_shapes = torch.as_tensor(img_shape, device=all_pred.device, dtype=torch.float32).reshape(-1, 2)
+        ret_val, yaw, t_vec, cov, cov_calib = pose_head.forward_decoded(dec, cam_intrinsic, img_shapes)
+        dims, dims_var = dec['dims'], dec['dims_var']
     if apply_cov_correction:
         kw = {k: decode_kw[k] for k in ('ref_length', 'ref_focal_y', 'target_std') if k in decode_kw}
         cov_calib = cov_correction(cov_calib, t_vec, **kw)
     return dict(ret_val=ret_val, yaw_pred=yaw, t_vec_pred=t_vec, pose_cov_pred=cov, pose_cov_calib=cov_calib,
-                dimensions_pred=dec['dims'], dimensions_var=dec['dims_var'])
+                dimensions_pred=dims, dimensions_var=dims_var)

@@ -118,7 +118,11 @@ def test_tail_end_to_end_two_launches(dev, orc):
         head.cov_calib_logscale.copy_(torch.from_numpy(logscale))
         t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
         res = pose_from_head(head, t(all_pred), t(labels), t(flip), t(dim), t(dim_var), t(b['rois']), t(b['K']), b['img_shape'])
+        res2 = pose_from_head(head, t(all_pred), t(labels), t(flip), t(dim), t(dim_var), t(b['rois']), t(b['K']), b['img_shape'], fused=False)
     torch.cuda.synchronize()
+    # ONE fused launch == K2 followed by the PnP kernel, bit for bit
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'dimensions_pred', 'dimensions_var'):
+        assert torch.equal(res[k], res2[k]), k
     assert np.array_equal(res['ret_val'].cpu().numpy(), ref[0])
     ok = ref[0]
     # istd goes through exp/log (few-ulp differences) before the bit-exact-thresholded mask, so compare poses, not masks
@@ -127,3 +131,31 @@ def test_tail_end_to_end_two_launches(dev, orc):
     assert np.median(dy) <= 1e-5 and dy.max() <= 2e-3
     rc = res['pose_cov_calib'].cpu().numpy()
     assert np.median(np.abs(rc - ref_calib)[ok] / np.abs(ref_calib)[ok].max((1, 2), keepdims=True)) <= 1e-4
+
+
+def test_fused_head_to_pose_matches_two_launches_everywhere(dev, g3):
+    """mr_pnp_from_head_batched (decode inside the PnP kernel, maps never in HBM) against noc_decode + PnPUncert
+    on the golden head output: identical valid / pose / cov / inlier mask / dims, incl. class-agnostic and no-variance."""
+    from monorun_amd.pose_head import noc_decode, pnp_from_head, _planar_view
+    from monorun_amd.ops import pnp_uncert
+    rng = np.random.default_rng(8)
+    B = g3['all_pred'].shape[0]
+    rois = np.stack([rng.uniform(100, 900, B), rng.uniform(50, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(30, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    K = t(syn.KITTI_K[None].astype(np.float32))
+    img = np.array([[375.0, 1242.0]], np.float32)
+    for agn, dv in ((False, g3['dim_var']), (False, None), (True, g3['dim_var'])):
+        ap = g3['all_pred'][:, :10] if agn else g3['all_pred']
+        lab = np.zeros(B, np.int64) if agn else g3['labels']
+        kw = dict(num_classes=1 if agn else 3, class_agnostic=agn)
+        out = pnp_from_head(t(ap), t(lab), t(g3['flip']), t(g3['dim']), t(dv) if dv is not None else None, t(rois), K, img,
+                            with_diag=True, **kw)
+        dec = noc_decode(t(ap), t(lab), t(g3['flip']), t(g3['dim']), t(dv) if dv is not None else None, t(rois), **kw)
+        ur = torch.tensor([[-200.0, 1442.0]], device=dev); vr = torch.tensor([[-200.0, 575.0]], device=dev)
+        ref = pnp_uncert(_planar_view(dec['coords_2d']), _planar_view(dec['coords_2d_istd']), _planar_view(dec['coords_3d']), K, ur, vr,
+                         0.5, 0.6, dec['ransac_thr'], True)
+        torch.cuda.synchronize()
+        for a, b_ in zip(out[:5], ref):
+            assert torch.equal(a, b_)
+        assert torch.equal(out[5], dec['dims']) and (dv is None or torch.equal(out[6], dec['dims_var']))
