@@ -12,6 +12,7 @@
   * ``pnp_from_head`` / ``pose_from_head`` — the whole post-NOC-head tail in ONE launch (K2 fused into the PnP kernel's
     load stage; the decoded maps never touch HBM), or two launches with ``fused=False``
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -23,6 +24,32 @@ NOC_MEANS = (-0.1, -0.5, 0.0)
 NOC_STDS = (0.35, 0.23, 0.34)
 DIM_MEANS = ((3.89, 1.53, 1.62), (0.82, 1.78, 0.63), (1.77, 1.72, 0.57))
 DIM_STDS = ((0.44, 0.14, 0.11), (0.25, 0.13, 0.12), (0.15, 0.10, 0.14))
+
+
+_CONST_CACHE = {}
+
+
+def _const(values, dev):
+    """Small constant tensors (coder means/stds, clip ranges) live on the device once per (device, value)."""
+    key = (str(dev), tuple(np.asarray(values, np.float32).ravel().tolist()), np.asarray(values).shape)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(np.asarray(values, np.float32), device=dev).contiguous()
+        _CONST_CACHE[key] = t
+    return t
+
+
+def _clip_ranges(img_shapes, allowed_border, dev):
+    """u_range = [-border, W + border], v_range = [-border, H + border] (uncert_prop_pnp_optimizer.py:75-80)."""
+    if torch.is_tensor(img_shapes) and img_shapes.device.type == 'cuda':
+        sh = img_shapes.to(torch.float32).reshape(-1, 2)
+        ur = sh.new_full((sh.size(0), 2), -float(allowed_border)); vr = ur.clone()
+        ur[:, 1] = sh[:, 1] + allowed_border; vr[:, 1] = sh[:, 0] + allowed_border
+        return ur, vr
+    sh = np.asarray(img_shapes.cpu() if torch.is_tensor(img_shapes) else img_shapes, np.float32).reshape(-1, 2)
+    ur = np.stack([np.full(len(sh), -float(allowed_border), np.float32), sh[:, 1] + allowed_border], 1)
+    vr = np.stack([np.full(len(sh), -float(allowed_border), np.float32), sh[:, 0] + allowed_border], 1)
+    return _const(ur, dev), _const(vr, dev)
 
 
 def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_agnostic=False,
@@ -54,8 +81,7 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
     dv = dim_var.detach().to(**f32).contiguous() if dim_var is not None else None
     r = rois.detach().to(**f32)
     r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
-    t = lambda v: torch.tensor(v, **f32).contiguous()
-    mu, sd, nm, ns = t(dim_means), t(dim_stds), t(noc_means), t(noc_stds)
+    mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
     assert mu.shape == sd.shape and mu.shape[1] == 3
     c2d = torch.empty(B, 2, h, w, **f32)
     istd = torch.empty(B, 2, h, w, **f32)
@@ -99,14 +125,9 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
     dv = dim_var.detach().to(**f32).contiguous() if dim_var is not None else None
     r = rois.detach().to(**f32)
     r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
-    t = lambda v: torch.tensor(v, **f32).contiguous()
-    mu, sd, nm, ns = t(dim_means), t(dim_stds), t(noc_means), t(noc_stds)
+    mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
     cam = cam_intrinsic.detach().to(**f32).reshape(-1, 3, 3).contiguous()
-    img_shapes = torch.as_tensor(img_shapes, device=dev, dtype=torch.float32).reshape(-1, 2)
-    ur = torch.full((img_shapes.size(0), 2), -float(allowed_border), **f32)
-    vr = torch.full((img_shapes.size(0), 2), -float(allowed_border), **f32)
-    ur[:, 1] = img_shapes[:, 1] + allowed_border
-    vr[:, 1] = img_shapes[:, 0] + allowed_border
+    ur, vr = _clip_ranges(img_shapes, allowed_border, dev)
     P = h * w
     valid = torch.empty(B, device=dev, dtype=torch.uint8)
     pose = torch.empty(B, 4, **f32); cov = torch.empty(B, 4, 4, **f32); tr = torch.empty(B, **f32)
