@@ -162,6 +162,44 @@ int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int3
                        float thr, int64_t *keep, int32_t *num_keep, void *stream);
 
 /*
+ * N2: KITTI object evaluator, device side — replaces the numba / numba-CUDA code of
+ * monorun/core/evaluation/kitti_utils/eval.py and rotate_iou.py.  All arrays are device pointers; images are addressed
+ * through exclusive prefix offsets (n_img+1 entries).  Box rows are double[12]:
+ *   x1 y1 x2 y2 (2-D box) | x y z (location, y = bottom) | l h w (dimensions) | rotation_y | score
+ *
+ * mr_kitti_overlaps: the per-image overlap blocks that eval_class reads (eval.py:477-479 -> calculate_iou_partly,
+ *   eval.py:341-416): overlaps[ov_off[i] + j*n_gt_i + k] for detection j and label k of image i.
+ *   metric 0 = image_box_overlap (eval.py:84-112), 1 = bev_box_overlap (rotate_iou.py:256-281, inputs rounded to float32,
+ *   result rounded to float32), 2 = d3_box_overlap (eval.py:121-158).  arith32: the annotation arrays were float32, so
+ *   numba's arithmetic was float32;  out32: results are stored in a float32 array.
+ */
+int mr_kitti_overlaps(int metric, int arith32, int out32, int n_img, const int64_t *dt_off, const int64_t *gt_off,
+                      const int64_t *ov_off, int64_t total_pairs, const double *dt_box, const double *gt_box,
+                      double *overlaps, void *stream);
+
+/*
+ * mr_kitti_match: compute_statistics_jit (eval.py:161-279) for every image and every "combo" = (class, difficulty,
+ *   min_overlap) at once.  ign_gt / ign_dt: int8 [n_cd][total] rows of clean_data's ignore codes (eval.py:28-80), one row
+ *   per (class, difficulty); combo_cd[c] selects the row, combo_min_overlap[c] the IoU threshold.
+ *   second_pass = 0 (compute_fp=False, eval.py:499-513): match_score [n_combo][total_gt] receives the score of the
+ *     detection matched to each true-positive label (entries of other labels are left untouched: pre-fill with NaN).
+ *   second_pass = 1 (fused_compute_statistics, eval.py:291-338): thresholds [n_combo][41] with n_thr[c] valid entries;
+ *     pr [n_combo][41][4] receives (tp, fp, fn, similarity) summed over the images in image order.  dc_box (total_dc,4) /
+ *     dc_off: DontCare regions (metric 0).  workspace: >= mr_kitti_match_workspace_bytes(n_img, n_combo) bytes.
+ *   alpha32 / dtdata32: the label+detection / detection arrays were float32 (numba's alpha difference and the DontCare
+ *   overlap are then float32).  max_det: largest number of detections in one image (<= 512).
+ */
+int64_t mr_kitti_match_workspace_bytes(int n_img, int n_combo);
+int mr_kitti_match(int second_pass, int metric, int compute_aos, int alpha32, int dtdata32, int n_img, int max_det,
+                   const int64_t *dt_off, const int64_t *gt_off, const int64_t *ov_off, const int64_t *dc_off,
+                   int64_t total_dt, int64_t total_gt,
+                   const double *overlaps, const double *dt_box, const double *dt_alpha, const double *gt_alpha,
+                   const double *dc_box, const int8_t *ign_gt, const int8_t *ign_dt,
+                   int n_combo, const int32_t *combo_cd, const double *combo_min_overlap,
+                   const double *thresholds, const int32_t *n_thr, double *match_score, double *pr,
+                   void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
  * N4: the two further entry points the reference's ext.h declares (ext.h:15-43,
  * pnp_uncert_cpu.cpp:294-377) — exported by the reference, never called by its Python code.  Same signatures
  * and semantics: dimpose = [log l, log h, log w, yaw, tx, ty, tz]; pts3d are NOC coordinates scaled by

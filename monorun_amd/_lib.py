@@ -29,7 +29,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
+    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(_HERE, "csrc", "kitti_eval_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -91,6 +91,14 @@ def load():
         f.argtypes = [dp, dp, dp, dp, dp, dp, dp, ctypes.POINTER(i32), dp, i32, dp, ctypes.c_double]
     lib.mr_nms_bev_batched.restype = i32
     lib.mr_nms_bev_batched.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
+    i64 = ctypes.c_int64
+    lib.mr_kitti_overlaps.restype = i32
+    lib.mr_kitti_overlaps.argtypes = [i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]
+    lib.mr_kitti_match_workspace_bytes.restype = i64
+    lib.mr_kitti_match_workspace_bytes.argtypes = [i32, i32]
+    lib.mr_kitti_match.restype = i32
+    lib.mr_kitti_match.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, i64,
+                                   vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     _lib = lib
     return lib
 
@@ -103,4 +111,5 @@ def check(code):
 
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
-                    'mr_pnp_uncert_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert')
+                    'mr_pnp_uncert_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert',
+                    'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match')

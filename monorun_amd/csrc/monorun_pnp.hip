@@ -265,6 +265,8 @@ __global__ void __launch_bounds__(256) nms_bev_kernel(const float *boxes, const 
     }
 }
 
+#include "kitti_eval_kernel.inc"
+
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
     n += sizeof(double) * 2 * wpo * kRedN;
@@ -538,6 +540,65 @@ int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int3
     hipLaunchKernelGGL(nms_bev_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, boxes_xyxyr, scores, (const int *)offsets, thr,
                        (long long *)keep, (int *)num_keep);
     HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
+// ---- N2: KITTI evaluator (eval.py / rotate_iou.py of core/evaluation/kitti_utils)
+int mr_kitti_overlaps(int metric, int arith32, int out32, int n_img, const int64_t *dt_off, const int64_t *gt_off, const int64_t *ov_off,
+                      int64_t total_pairs, const double *dt_box, const double *gt_box, double *overlaps, void *stream) {
+    if (metric < 0 || metric > 2 || n_img < 0 || total_pairs < 0) return MR_ERR_BAD_ARGUMENT;
+    if (n_img == 0 || total_pairs == 0) return MR_OK;
+    if (!dt_off || !gt_off || !ov_off || !dt_box || !gt_box || !overlaps) return MR_ERR_BAD_ARGUMENT;
+    const long long blocks = (total_pairs + 255) / 256;
+    if (blocks > 0x7fffffffLL) return MR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kitti_overlap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, metric, arith32, out32, n_img,
+                       (const long long *)dt_off, (const long long *)gt_off, (const long long *)ov_off, dt_box, gt_box, overlaps);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
+int64_t mr_kitti_match_workspace_bytes(int n_img, int n_combo) {
+    if (n_img < 0 || n_combo < 0) return 0;
+    return (int64_t)n_combo * kEvalSamples * (int64_t)n_img * (3 * sizeof(int) + sizeof(double)) + 64;
+}
+
+int mr_kitti_match(int second_pass, int metric, int compute_aos, int alpha32, int dtdata32, int n_img, int max_det,
+                   const int64_t *dt_off, const int64_t *gt_off, const int64_t *ov_off, const int64_t *dc_off,
+                   int64_t total_dt, int64_t total_gt,
+                   const double *overlaps, const double *dt_box, const double *dt_alpha, const double *gt_alpha, const double *dc_box,
+                   const int8_t *ign_gt, const int8_t *ign_dt, int n_combo, const int32_t *combo_cd, const double *combo_min_overlap,
+                   const double *thresholds, const int32_t *n_thr, double *match_score, double *pr,
+                   void *workspace, int64_t workspace_bytes, void *stream) {
+    if (n_img < 0 || n_combo < 0 || metric < 0 || metric > 2) return MR_ERR_BAD_ARGUMENT;
+    if (n_img == 0 || n_combo == 0) return MR_OK;
+    if (max_det > kEvalMaxDet) return MR_ERR_UNSUPPORTED;
+    if (!dt_off || !gt_off || !ov_off || !dc_off || !ign_gt || !ign_dt || !combo_cd || !combo_min_overlap) return MR_ERR_BAD_ARGUMENT;
+    MatchArgs a;
+    a.second_pass = second_pass; a.metric = metric; a.compute_aos = compute_aos; a.alpha32 = alpha32; a.dtdata32 = dtdata32;
+    a.n_img = n_img; a.n_combo = n_combo; a.total_gt = total_gt; a.total_dt = total_dt;
+    a.dt_off = (const long long *)dt_off; a.gt_off = (const long long *)gt_off; a.ov_off = (const long long *)ov_off; a.dc_off = (const long long *)dc_off;
+    a.ov = overlaps; a.dt_box = dt_box; a.dt_alpha = dt_alpha; a.gt_alpha = gt_alpha; a.dc_box = dc_box;
+    a.ign_gt = (const signed char *)ign_gt; a.ign_dt = (const signed char *)ign_dt;
+    a.combo_cd = (const int *)combo_cd; a.combo_min_overlap = combo_min_overlap;
+    a.thresholds = thresholds; a.n_thr = (const int *)n_thr; a.match_score = match_score;
+    a.st_tp = a.st_fp = a.st_fn = nullptr; a.st_sim = nullptr;
+    long long threads = (long long)n_combo * n_img;
+    if (second_pass) {
+        if (!thresholds || !n_thr || !pr || !workspace || workspace_bytes < mr_kitti_match_workspace_bytes(n_img, n_combo)) return MR_ERR_BAD_ARGUMENT;
+        const long long cells = (long long)n_combo * kEvalSamples * n_img;
+        a.st_sim = (double *)workspace;                       // doubles first (alignment), then the three int planes
+        a.st_tp = (int *)(a.st_sim + cells); a.st_fp = a.st_tp + cells; a.st_fn = a.st_fp + cells;
+        threads *= kEvalSamples;
+    } else if (!match_score) return MR_ERR_BAD_ARGUMENT;
+    const long long blocks = (threads + 127) / 128;
+    if (blocks > 0x7fffffffLL) return MR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kitti_match_kernel, dim3((unsigned)blocks), dim3(128), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    if (second_pass) {
+        hipLaunchKernelGGL(kitti_reduce_kernel, dim3((n_combo * kEvalSamples + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_img, n_combo,
+                           (const int *)n_thr, a.st_tp, a.st_fp, a.st_fn, a.st_sim, pr);
+        HIP_TRY(hipGetLastError());
+    }
     return MR_OK;
 }
 

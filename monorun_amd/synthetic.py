@@ -143,3 +143,130 @@ def pnp_boundary(batch, allowed_border=200, ransac_ratio=0.2, std_scale=10.0, pl
         v = a.reshape(B, a.shape[1], h * w).transpose(0, 2, 1)
         return v if planar else np.ascontiguousarray(v)
     return view(c2d), view(istd), view(c3d), batch['K'], u_range, v_range, thr
+
+
+# ---------------------------------------------------------------------------------------------------
+# KITTI-style annotations for the evaluator (N2).  No dataset is reachable offline, so the evaluator is
+# exercised on synthetic label / detection sets in the exact dict format the reference's evaluator reads
+# (kitti3d_dataset.py:230-305: name, truncated, occluded, alpha, bbox, dimensions [l,h,w], location
+# [x, y(bottom), z] in the camera frame, rotation_y, score).
+KITTI_K = np.array([[707.0912, 0.0, 601.8873], [0.0, 707.0912, 183.1104], [0.0, 0.0, 1.0]])
+_KITTI_DIMS = {  # mean l, h, w
+    'Car': (3.89, 1.53, 1.62), 'Van': (5.08, 2.21, 1.90), 'Pedestrian': (0.84, 1.76, 0.66),
+    'Person_sitting': (0.80, 1.27, 0.59), 'Cyclist': (1.76, 1.74, 0.60),
+}
+
+
+def _kitti_bbox(loc, dims, ry, K=KITTI_K, img_wh=(1242, 375)):
+    l, h, w = dims
+    xc = np.array([l, l, -l, -l, l, l, -l, -l]) / 2
+    yc = np.array([0, 0, 0, 0, -h, -h, -h, -h], np.float64)
+    zc = np.array([w, -w, -w, w, w, -w, -w, w]) / 2
+    c, s = np.cos(ry), np.sin(ry)
+    X = np.stack([c * xc + s * zc + loc[0], yc + loc[1], -s * xc + c * zc + loc[2]])
+    X[2] = np.maximum(X[2], 0.1)
+    uv = (K @ X)[:2] / X[2]
+    x1, y1, x2, y2 = uv[0].min(), uv[1].min(), uv[0].max(), uv[1].max()
+    full = max(x2 - x1, 1e-6) * max(y2 - y1, 1e-6)
+    x1c, y1c, x2c, y2c = np.clip(x1, 0, img_wh[0] - 1), np.clip(y1, 0, img_wh[1] - 1), np.clip(x2, 0, img_wh[0] - 1), np.clip(y2, 0, img_wh[1] - 1)
+    vis = max(x2c - x1c, 0) * max(y2c - y1c, 0)
+    return np.array([x1c, y1c, x2c, y2c]), float(1.0 - vis / full)
+
+
+def make_kitti_annos(n_img=60, seed=7, max_gt=7, dtype=np.float32):
+    """Synthetic (gt_annos, dt_annos) lists: jittered detections of most labels, class confusions, false positives,
+    DontCare regions with detections inside them, empty images, all three difficulty regimes."""
+    rng = np.random.default_rng(seed)
+    names = ['Car', 'Car', 'Car', 'Pedestrian', 'Pedestrian', 'Cyclist', 'Cyclist', 'Van', 'Person_sitting']
+    gts, dts = [], []
+    for _ in range(n_img):
+        n_obj = int(rng.integers(0, max_gt + 1))
+        g = dict(name=[], truncated=[], occluded=[], alpha=[], bbox=[], dimensions=[], location=[], rotation_y=[])
+        d = dict(name=[], alpha=[], bbox=[], dimensions=[], location=[], rotation_y=[], score=[])
+        for _o in range(n_obj):
+            nm = names[int(rng.integers(len(names)))]
+            dims = np.array(_KITTI_DIMS[nm]) * rng.uniform(0.85, 1.15, 3)
+            z = rng.uniform(5, 45); x = rng.uniform(-0.55, 0.55) * z; y = rng.uniform(1.4, 1.9)
+            ry = rng.uniform(-np.pi, np.pi)
+            loc = np.array([x, y, z])
+            bbox, trunc = _kitti_bbox(loc, dims, ry)
+            if bbox[2] - bbox[0] < 4 or bbox[3] - bbox[1] < 4:
+                continue
+            occ = int(rng.choice([0, 0, 0, 1, 1, 2, 3]))
+            g['name'].append(nm); g['truncated'].append(min(trunc + rng.uniform(0, 0.05), 1.0)); g['occluded'].append(occ)
+            g['alpha'].append(ry - np.arctan2(x, z)); g['bbox'].append(bbox); g['dimensions'].append(dims)
+            g['location'].append(loc); g['rotation_y'].append(ry)
+            if rng.uniform() < 0.85:                     # detected
+                q = 1.0 - rng.beta(1.2, 3.5)               # quality (mostly good, a tail of poor localisations)
+                sig = 0.05 + 0.5 * (1 - q)
+                dloc = loc + rng.normal(0, sig, 3) * np.array([1, 0.3, 1.5])
+                ddim = dims * rng.uniform(1 - 0.1 * (1 - q) - 0.01, 1 + 0.1 * (1 - q) + 0.01, 3)
+                dry = ry + rng.normal(0, 0.02 + 0.25 * (1 - q))
+                dbox = bbox + rng.normal(0, 0.5 + 4 * (1 - q), 4)
+                dn = nm if rng.uniform() < 0.93 else ['Car', 'Pedestrian', 'Cyclist'][int(rng.integers(3))]
+                if dn in ('Van', 'Person_sitting'):
+                    dn = 'Car' if dn == 'Van' else 'Pedestrian'
+                d['name'].append(dn); d['alpha'].append(dry - np.arctan2(dloc[0], dloc[2] + 0.27)); d['bbox'].append(dbox)
+                d['dimensions'].append(ddim); d['location'].append(dloc); d['rotation_y'].append(dry)
+                d['score'].append(np.clip(0.15 + 0.8 * q + rng.normal(0, 0.05), 0.01, 0.999))
+        n_dc = int(rng.integers(0, 3))
+        for _o in range(n_dc):
+            x1 = rng.uniform(0, 1100); y1 = rng.uniform(120, 250); w = rng.uniform(30, 140); h = rng.uniform(20, 90)
+            g['name'].append('DontCare'); g['truncated'].append(-1); g['occluded'].append(-1); g['alpha'].append(-10)
+            g['bbox'].append(np.array([x1, y1, x1 + w, y1 + h])); g['dimensions'].append(np.full(3, -1.0))
+            g['location'].append(np.full(3, -1000.0)); g['rotation_y'].append(-10)
+            if rng.uniform() < 0.7:                      # a detection inside the DontCare region
+                nm = ['Car', 'Pedestrian', 'Cyclist'][int(rng.integers(3))]
+                dims = np.array(_KITTI_DIMS[nm]); z = rng.uniform(40, 70)
+                bx = np.array([x1 + 0.2 * w, y1 + 0.2 * h, x1 + 0.8 * w, y1 + 0.8 * h])
+                xx = (0.5 * (bx[0] + bx[2]) - KITTI_K[0, 2]) * z / KITTI_K[0, 0]
+                ry = rng.uniform(-np.pi, np.pi)
+                d['name'].append(nm); d['alpha'].append(ry - np.arctan2(xx, z + 0.27)); d['bbox'].append(bx)
+                d['dimensions'].append(dims); d['location'].append(np.array([xx, 1.6, z])); d['rotation_y'].append(ry)
+                d['score'].append(rng.uniform(0.05, 0.6))
+        for _o in range(int(rng.integers(0, 3))):          # false positives
+            nm = ['Car', 'Pedestrian', 'Cyclist'][int(rng.integers(3))]
+            dims = np.array(_KITTI_DIMS[nm]) * rng.uniform(0.9, 1.1, 3)
+            z = rng.uniform(5, 60); x = rng.uniform(-0.5, 0.5) * z; ry = rng.uniform(-np.pi, np.pi)
+            loc = np.array([x, rng.uniform(1.4, 1.9), z])
+            bbox, _t = _kitti_bbox(loc, dims, ry)
+            d['name'].append(nm); d['alpha'].append(ry - np.arctan2(x, z + 0.27)); d['bbox'].append(bbox)
+            d['dimensions'].append(dims); d['location'].append(loc); d['rotation_y'].append(ry)
+            d['score'].append(rng.uniform(0.02, 0.7))
+
+        def arr(v, shape):
+            return np.asarray(v, dtype).reshape(shape)
+        ng, nd = len(g['name']), len(d['name'])
+        gts.append(dict(name=np.array(g['name'], dtype='<U16'), truncated=arr(g['truncated'], (ng,)), occluded=arr(g['occluded'], (ng,)),
+                        alpha=arr(g['alpha'], (ng,)), bbox=arr(g['bbox'], (ng, 4)), dimensions=arr(g['dimensions'], (ng, 3)),
+                        location=arr(g['location'], (ng, 3)), rotation_y=arr(g['rotation_y'], (ng,)), score=np.zeros(ng, dtype)))
+        order = np.argsort(-np.asarray(d['score'], np.float64), kind='stable') if nd else np.zeros(0, np.int64)
+        dts.append(dict(name=np.array(d['name'], dtype='<U16')[order], truncated=np.full(nd, -1, np.int8), occluded=np.full(nd, -1, np.int8),
+                        alpha=arr(d['alpha'], (nd,))[order], bbox=arr(d['bbox'], (nd, 4))[order], dimensions=arr(d['dimensions'], (nd, 3))[order],
+                        location=arr(d['location'], (nd, 3))[order], rotation_y=arr(d['rotation_y'], (nd,))[order], score=arr(d['score'], (nd,))[order]))
+    return gts, dts
+
+
+_ANNO_FLOAT_KEYS = ('truncated', 'occluded', 'alpha', 'bbox', 'dimensions', 'location', 'rotation_y', 'score')
+
+
+def pack_kitti_annos(annos, prefix):
+    """list of annotation dicts -> flat arrays (for .npz fixtures)."""
+    out = {prefix + 'count': np.array([len(a['name']) for a in annos], np.int64),
+           prefix + 'name': np.concatenate([np.asarray(a['name'], dtype='<U16') for a in annos]) if annos else np.zeros(0, '<U16')}
+    for k in _ANNO_FLOAT_KEYS:
+        out[prefix + k] = np.concatenate([np.asarray(a[k]) for a in annos], 0)
+    return out
+
+
+def unpack_kitti_annos(z, prefix):
+    cnt = z[prefix + 'count']
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    annos = []
+    for i in range(len(cnt)):
+        s = slice(off[i], off[i + 1])
+        a = dict(name=z[prefix + 'name'][s].copy())
+        for k in _ANNO_FLOAT_KEYS:
+            a[k] = z[prefix + k][s].copy()
+        annos.append(a)
+    return annos

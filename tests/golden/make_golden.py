@@ -14,6 +14,7 @@ package __init__ cannot be imported — it pulls the unbuilt cffi `_ext`, cv2, m
   models/.../dense_decoders/fcn_noc_decoder.py::slice_pred . G3      (R9)  via mmcv/mmdet stubs
   models/.../optimizers/uncert_prop_pnp_optimizer.py ....... G4      (R8)  via mmdet stubs + a recording PnP
   core/bbox_3d/iou_calculators/rotate_iou_kernel.py ........ G5      (N1)  rotated IoU device functions via a numba stub
+  core/evaluation/kitti_utils/{eval,rotate_iou}.py ........ G6      (N2)  KITTI evaluator as plain Python under a numba stub
 """
 import importlib.util
 import os
@@ -299,6 +300,60 @@ def make_g5():
     print('G5: rotated IoU pairs', n, 'mean', iou.mean().round(4), 'zeros', (iou == 0).sum(), 'ones', (np.abs(iou - 1) < 1e-6).sum())
 
 
+# ------------------------------------------------------------------------------- G6 ------------
+def make_g6():
+    """KITTI evaluator (N2): the reference's own core/evaluation/kitti_utils/eval.py executed as plain Python under a
+    numba stub on a synthetic label/detection set; its numba-CUDA rotated-IoU launch (rotate_iou.py:340-378) is
+    replaced by a loop over pairs that calls the file's own device function devRotateIoUEval with the kernel's
+    argument order (query box first, rotate_iou.py:335-337)."""
+    nb = _pkg('numba')
+    cu = _pkg('numba.cuda')
+
+    def _jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    nb.jit = _jit; cu.jit = _jit; nb.cuda = cu; nb.prange = range
+    nb.float32 = np.float32; nb.int32 = np.int32
+    cu.local = types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype))
+    cu.shared = cu.local
+    _pkg('monorun.core.evaluation'); _pkg('monorun.core.evaluation.kitti_utils')
+    riou = _load('monorun.core.evaluation.kitti_utils.rotate_iou', 'core/evaluation/kitti_utils/rotate_iou.py')
+    ev = _load('monorun.core.evaluation.kitti_utils.eval', 'core/evaluation/kitti_utils/eval.py')
+
+    def rotate_iou_eval(boxes, query_boxes, criterion=-1, device_id=0):
+        boxes = boxes.astype(np.float32); query_boxes = query_boxes.astype(np.float32)
+        out = np.zeros((boxes.shape[0], query_boxes.shape[0]), np.float32)
+        for n in range(boxes.shape[0]):
+            for k in range(query_boxes.shape[0]):
+                out[n, k] = riou.devRotateIoUEval(query_boxes[k], boxes[n], criterion)
+        return out.astype(boxes.dtype)
+    riou.rotate_iou_gpu_eval = rotate_iou_eval
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
+    from monorun_amd import synthetic as syn
+    gts, dts = syn.make_kitti_annos(n_img=60, seed=7)
+    out = {}
+    out.update(syn.pack_kitti_annos(gts, 'gt_')); out.update(syn.pack_kitti_annos(dts, 'dt_'))
+    classes = ['Car', 'Pedestrian', 'Cyclist']
+    for crit in ('R40', 'R11'):
+        text, d = ev.kitti_eval(gts, dts, classes, eval_types=['bbox', 'bev', '3d'], criteria=crit)
+        out['text_' + crit] = np.array(text)
+        out['dict_keys_' + crit] = np.array(sorted(d.keys()))
+        out['dict_vals_' + crit] = np.array([d[k] for k in sorted(d.keys())], np.float64)
+    # kitti_eval_coco_style (eval.py:772-842) cannot run: np.linspace(*float_array) (eval.py:634) raises on numpy >= 1.18 and
+    # do_eval receives a bool where it iterates eval_types (eval.py:636-638); it is never called by the pipeline.
+    mo = np.stack([np.array([[0.7, 0.5, 0.5]] * 3), np.array([[0.7, 0.5, 0.5], [0.5, 0.25, 0.25], [0.5, 0.25, 0.25]])], 0)
+    for metric in (0, 1, 2):
+        ret = ev.eval_class(gts, dts, [0, 1, 2], [0, 1, 2], metric, mo, compute_aos=(metric == 0))
+        for k in ('precision', 'recall', 'orientation'):
+            out[f'm{metric}_{k}'] = ret[k]
+        ov = ev.calculate_iou_partly(dts, gts, metric, num_parts=60)[0]
+        out[f'm{metric}_overlaps'] = np.concatenate([o.reshape(-1) for o in ov]).astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g6_kitti_eval.npz'), **out)
+    print('G6: KITTI eval\n' + str(out['text_R40']))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     ref = load_reference()
@@ -306,6 +361,7 @@ if __name__ == '__main__':
     make_g3(ref)
     make_g4(ref)
     make_g5()
+    make_g6()
     for f in sorted(os.listdir(OUT)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')
