@@ -112,8 +112,12 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # MR_BENCH_FORCE_DIST=1 runs the RCCL path (init, all-gather, barrier, max-reduce) even at world size 1 — the only way
+    # to exercise it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get('MR_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     # synthetic config-2 batch for this rank (different objects per rank: seed + rank), resident in HBM
@@ -123,15 +127,15 @@ def main():
     packed = PackedResults(B_PER_GPU, dev)
     launch = PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr,
                        inlier_opt_only=True, flags=(args.waves << 8), out=packed)
-    gathered = torch.empty(world * packed.buf.numel(), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * packed.buf.numel(), dtype=torch.uint8, device=dev) if use_dist else None
 
     def step():
         launch.run()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, packed.buf)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +147,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -245,7 +249,7 @@ def main():
             line['speedup_vs_cpu_1thread'] = line['value'] / one['value']
             line['speedup_vs_cpu_all_cores'] = line['value'] / allc['value']
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
