@@ -236,6 +236,7 @@ def main():
                        'parallelism': f'objects sharded x{world}' + (', 1 RCCL all-gather of 88 B/object per step' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
+                         'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)),
                          'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU, 'valu_issue': valu,
                          'note': 'formally HBM-bound (read-once streaming); in practice VALU/latency-bound: the tile is LDS-resident '
                                  'across all LM iterations (DESIGN.md)'},

@@ -56,7 +56,10 @@ summ = dict(tag=tag, kernel=meta, rocprof_kernel_avg_us=float(stats['AverageNs']
                          wait_any_frac=counters['SQ_WAIT_ANY']['mean'] / counters['SQ_WAVE_CYCLES']['mean'],
                          wait_inst_frac=counters['SQ_WAIT_INST_ANY']['mean'] / counters['SQ_WAVE_CYCLES']['mean'],
                          lds_bank_conflict_frac=counters['SQ_LDS_BANK_CONFLICT']['mean'] / counters['SQ_LDS_IDX_ACTIVE']['mean'],
-                         waves_per_launch=counters['SQ_WAVES']['mean']))
+                         waves_per_launch=counters['SQ_WAVES']['mean'],
+                         # SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md); divided by the launch's
+                         # cycles on 1024 SIMDs (at the 2.4 GHz peak clock: a LOWER bound of the occupancy if the clock was lower)
+                         mean_resident_waves_per_simd=4.0 * counters['SQ_WAVE_CYCLES']['mean'] / (float(stats['AverageNs']) / 1e3 * 2400.0 * 1024)))
 json.dump(summ, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
 print(json.dumps(summ['derived'], indent=1)); print(json.dumps(traffic, indent=1))
 print('rocprof avg us', summ['rocprof_kernel_avg_us'], 'bench events avg us', summ['bench_kernel_avg_us'])
