@@ -116,6 +116,10 @@ void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *
  * writes channel-planar maps
  *   coords_2d (B,2,h,w), coords_2d_istd (B,2,h,w), coords_3d (B,3,h,w)   [all f32]
  *   dims (B,3), dims_var (B,3) (optional), ransac_thr (B) (optional)
+ * coords_2d = roi_align(coord_2d, rois, (h,w), 1.0, 0, 'avg', True) (monorun_roi_head.py:521-523).  With
+ *   coord_2d_map == NULL the map is taken to be the identity pixel grid of the image the RoIs live in (test configs:
+ *   scale_factor 1.0, no flip) and the bin centres are written analytically; with a (2,H,W) map (loading.py:67-78 after
+ *   Resize3D / RandomFlip3D / Pad3D) the RoIAlign taps are sampled exactly, mmcv border rules included.
  */
 int mr_noc_decode_batched(
     const float *all_pred, const int64_t *labels, const uint8_t *flip,
@@ -127,6 +131,7 @@ int mr_noc_decode_batched(
     float std_scale, float ransac_thres_ratio /* <0: ransac_thr not written */,
     float *coords_2d, float *coords_2d_istd, float *coords_3d,
     float *dims, float *dims_var, float *ransac_thr,
+    const float *coord_2d_map /* (2,H,W) device map or NULL */, int map_h, int map_w,
     void *stream);
 
 /*
@@ -146,7 +151,15 @@ int mr_pnp_from_head_batched(
     const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
-    float *dims, float *dims_var, void *stream);
+    float *dims, float *dims_var, const float *coord_2d_map, int map_h, int map_w, void *stream);
+
+/*
+ * N3: RoIAlign forward, average pooling — mmcv.ops.roi_align(input, rois, (out_h,out_w), spatial_scale, sampling_ratio,
+ * 'avg', aligned) as called at monorun_roi_head.py:521-523 (mmcv is third-party and absent; published algorithm).
+ * input (N,C,H,W) f32, rois (K,5) [batch_idx, x1, y1, x2, y2], output (K,C,out_h,out_w).  sampling_ratio 0 = adaptive.
+ */
+int mr_roi_align_avg(const float *input, const float *rois, int K, int C, int H, int W, int out_h, int out_w,
+                     float spatial_scale, int sampling_ratio, int aligned, float *output, void *stream);
 
 /*
  * N1: rotated-BEV NMS of the pose consumers — replaces mmdet3d.ops.iou3d.nms_gpu as called by

@@ -78,13 +78,15 @@ def load():
         lib.mr_noc_decode_batched.argtypes = [
             vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
             vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
-            vp, vp, vp, vp, vp, vp, vp]
+            vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.mr_pnp_from_head_batched.restype = i32
     lib.mr_pnp_from_head_batched.argtypes = [
         vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
         vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
         vp, i32, vp, vp, i32, f32, f32, i32, i32,
-        vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    lib.mr_roi_align_avg.restype = i32
+    lib.mr_roi_align_avg.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp]
     for name in ('pnp_noc_uncert', 'pnp_noc_cov_uncert'):
         f = getattr(lib, name)
         f.restype = None
@@ -112,4 +114,4 @@ def check(code):
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
                     'mr_pnp_uncert_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert',
-                    'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match')
+                    'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

@@ -38,9 +38,62 @@ struct DecodeArgs {
     const float *dim_means, *dim_stds; float noc_mean[3], noc_std[3];
     float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
     float *c2d, *istd, *c3d, *dims, *dims_var, *thr;
+    const float *map2d; int map_h, map_w;      // optional coord_2d map (2, H, W): exact RoIAlign sampling instead of the analytic grid
 };
 
-struct DecodeObj { float dm[3], dv[3]; float x1, y1, su, sv, thr; const float *base; int ch_noc, ch_ls; };
+// RoIAlign forward, average pooling (mmcv.ops.roi_align: the published Detectron/mmcv algorithm, mmcv 1.2.1
+// roi_align_cuda_kernel.cuh — third-party, not in the reference tree): bilinear taps with mmcv's border rules
+// (a sample more than one pixel outside contributes 0; otherwise it is clamped into [0, size-1]).
+__device__ __forceinline__ float roi_bilinear(const float *in, int H, int W, float y, float x) {
+#pragma clang fp contract(off)
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.0f;
+    if (y <= 0.0f) y = 0.0f;
+    if (x <= 0.0f) x = 0.0f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float v1 = in[y_low * W + x_low], v2 = in[y_low * W + x_high], v3 = in[y_high * W + x_low], v4 = in[y_high * W + x_high];
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+// one output bin (ph, pw) of one channel; roi = x1 y1 x2 y2 already multiplied by spatial_scale
+__device__ __forceinline__ float roi_align_avg_bin(const float *in, int H, int W, float x1, float y1, float x2, float y2,
+                                                   int ph, int pw, int out_h, int out_w, int sampling_ratio, int aligned) {
+#pragma clang fp contract(off)
+    const float off = aligned ? 0.5f : 0.0f;
+    const float sw = x1 - off, sh = y1 - off;
+    float rw = (x2 - off) - sw, rh = (y2 - off) - sh;
+    if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+    const float bh = rh / (float)out_h, bw = rw / (float)out_w;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)out_h);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)out_w);
+    const float count = (float)max(gh * gw, 1);
+    float acc = 0.0f;
+    for (int iy = 0; iy < gh; ++iy) {
+        const float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+            acc += roi_bilinear(in, H, W, y, x);
+        }
+    }
+    return acc / count;
+}
+
+__global__ void __launch_bounds__(256) roi_align_avg_kernel(const float *in, const float *rois, int K, int C, int H, int W, int out_h, int out_w,
+                                                            float spatial_scale, int sampling_ratio, int aligned, float *out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)K * C * out_h * out_w) return;
+    const int pw = (int)(idx % out_w), ph = (int)((idx / out_w) % out_h), c = (int)((idx / ((long long)out_w * out_h)) % C);
+    const int n = (int)(idx / ((long long)out_w * out_h * C));
+    const float *r = rois + (long long)n * 5;
+    const int bi = (int)r[0];
+    out[idx] = roi_align_avg_bin(in + ((long long)bi * C + c) * H * W, H, W, r[1] * spatial_scale, r[2] * spatial_scale, r[3] * spatial_scale,
+                                 r[4] * spatial_scale, ph, pw, out_h, out_w, sampling_ratio, aligned);
+}
+
+struct DecodeObj { float dm[3], dv[3]; float x1, y1, x2, y2, su, sv, thr; const float *base; int ch_noc, ch_ls; };
 
 __device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, DecodeObj &o) {
 #pragma clang fp contract(off)
@@ -58,7 +111,15 @@ __device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, Decode
     const float x1 = a.rois[b * 4 + 0], y1 = a.rois[b * 4 + 1], x2 = a.rois[b * 4 + 2], y2 = a.rois[b * 4 + 3];
     o.x1 = x1; o.y1 = y1;
     o.su = (x2 - x1) / (float)a.w; o.sv = (y2 - y1) / (float)a.h;
-    const float v_last = (y1 - 0.5f) + ((float)(a.h - 1) + 0.5f) * o.sv, v_first = (y1 - 0.5f) + 0.5f * o.sv;
+    o.x2 = x2; o.y2 = y2;
+    float v_last, v_first;
+    if (a.map2d) {      // x2d[:, 1, -1, 0] - x2d[:, 1, 0, 0] of the sampled map (uncert_prop_pnp_optimizer.py:86-88)
+        const float *mv = a.map2d + (long long)a.map_h * a.map_w;
+        v_last = roi_align_avg_bin(mv, a.map_h, a.map_w, x1, y1, x2, y2, a.h - 1, 0, a.h, a.w, 0, 1);
+        v_first = roi_align_avg_bin(mv, a.map_h, a.map_w, x1, y1, x2, y2, 0, 0, a.h, a.w, 0, 1);
+    } else {
+        v_last = (y1 - 0.5f) + ((float)(a.h - 1) + 0.5f) * o.sv; v_first = (y1 - 0.5f) + 0.5f * o.sv;
+    }
     o.thr = a.ratio * (v_last - v_first);
     o.base = a.all_pred + (long long)b * (2 * Cn * 5) * hw;
     o.ch_noc = f * 5 * Cn + 3 * c; o.ch_ls = f * 5 * Cn + 3 * Cn + 2 * c;
@@ -85,8 +146,13 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
         else lspx = ls + 0.0f;                                    // log(sd / sd)
         istd[k] = expf(-lspx) / a.std_scale;
     }
-    c2d[0] = (o.x1 - 0.5f) + ((float)px + 0.5f) * o.su;
-    c2d[1] = (o.y1 - 0.5f) + ((float)py + 0.5f) * o.sv;
+    if (a.map2d) {      // roi_align(coord_2d, rois, (h, w), 1.0, 0, 'avg', True)   (monorun_roi_head.py:521-523)
+        c2d[0] = roi_align_avg_bin(a.map2d, a.map_h, a.map_w, o.x1, o.y1, o.x2, o.y2, py, px, a.h, a.w, 0, 1);
+        c2d[1] = roi_align_avg_bin(a.map2d + (long long)a.map_h * a.map_w, a.map_h, a.map_w, o.x1, o.y1, o.x2, o.y2, py, px, a.h, a.w, 0, 1);
+    } else {            // interior analytic form: the bin centre of an identity coordinate map
+        c2d[0] = (o.x1 - 0.5f) + ((float)px + 0.5f) * o.su;
+        c2d[1] = (o.y1 - 0.5f) + ((float)py + 0.5f) * o.sv;
+    }
 }
 
 __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
@@ -476,8 +542,10 @@ int mr_noc_decode_batched(
     int B, int num_classes, int class_agnostic, int h, int w,
     const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
     double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
-    float *coords_2d, float *coords_2d_istd, float *coords_3d, float *dims, float *dims_var, float *ransac_thr, void *stream) {
+    float *coords_2d, float *coords_2d_istd, float *coords_3d, float *dims, float *dims_var, float *ransac_thr,
+    const float *coord_2d_map, int map_h, int map_w, void *stream) {
     if (B == 0) return MR_OK;
+    if (coord_2d_map && (map_h < 1 || map_w < 1)) return MR_ERR_BAD_ARGUMENT;
     if (B > 65535) return MR_ERR_BAD_ARGUMENT;
     DecodeArgs a;
     const int rc = fill_decode_args(a, all_pred, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
@@ -486,6 +554,7 @@ int mr_noc_decode_batched(
     if (!coords_2d || !coords_2d_istd || !coords_3d) return MR_ERR_BAD_ARGUMENT;
     a.c2d = coords_2d; a.istd = coords_2d_istd; a.c3d = coords_3d; a.dims = dims; a.dims_var = dims_var;
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
+    a.map2d = coord_2d_map; a.map_h = map_h; a.map_w = map_w;
     const int hw = h * w;
     hipLaunchKernelGGL(noc_decode_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -500,9 +569,10 @@ int mr_pnp_from_head_batched(
     const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
-    float *dims, float *dims_var, void *stream) {
+    float *dims, float *dims_var, const float *coord_2d_map, int map_h, int map_w, void *stream) {
     const int P = h * w;
     if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
+    if (coord_2d_map && (map_h < 1 || map_w < 1)) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!cam_mats || !u_range || !v_range || !valid || !pose || !tr_radius || (!cov && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
     if ((cam_batch != 1 && cam_batch != B) || (range_batch != 1 && range_batch != B)) return MR_ERR_BAD_ARGUMENT;
@@ -512,6 +582,7 @@ int mr_pnp_from_head_batched(
                                     noc_means, noc_stds, proj_scaling_denominator, ref_focal_y, epistemic_std_gain, std_scale, ransac_thres_ratio);
     if (rc != MR_OK) return rc;
     a.dec.dims = dims; a.dec.dims_var = dims_var;
+    a.dec.map2d = coord_2d_map; a.dec.map_h = map_h; a.dec.map_w = map_w;
     a.from_head = 1;
     // the tile is built channel-planar, exactly the layout (and hence numpy summation order) the reference's head produces
     a.s2[0] = 2LL * P; a.s2[1] = 1; a.s2[2] = P; a.sw[0] = 2LL * P; a.sw[1] = 1; a.sw[2] = P; a.s3[0] = 3LL * P; a.s3[1] = 1; a.s3[2] = P;
@@ -527,6 +598,19 @@ int mr_pnp_from_head_batched(
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
     return launch_wpo<float>(a, pick_wpo(B, P, flags), (hipStream_t)stream);
+}
+
+int mr_roi_align_avg(const float *input, const float *rois, int K, int C, int H, int W, int out_h, int out_w,
+                     float spatial_scale, int sampling_ratio, int aligned, float *output, void *stream) {
+    if (K < 0 || C < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1) return MR_ERR_BAD_ARGUMENT;
+    if (K == 0) return MR_OK;
+    if (!input || !rois || !output) return MR_ERR_BAD_ARGUMENT;
+    const long long n = (long long)K * C * out_h * out_w, blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return MR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(roi_align_avg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, input, rois, K, C, H, W, out_h, out_w,
+                       spatial_scale, sampling_ratio, aligned, output);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
 }
 
 int mr_nms_bev_batched(const float *boxes_xyxyr, const float *scores, const int32_t *offsets, int groups, int max_group,

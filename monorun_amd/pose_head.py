@@ -52,14 +52,47 @@ def _clip_ranges(img_shapes, allowed_border, dev):
     return _const(ur, dev), _const(vr, dev)
 
 
+def _coord_map_args(coord_2d, dev):
+    """(pointer, H, W) of the optional coord_2d map for the C ABI.  A converted copy may be released as soon as this
+    returns: the caching allocator is stream-ordered and the launch that reads it is the next thing enqueued."""
+    if coord_2d is None:
+        return None, 0, 0
+    m = coord_2d.detach().to(device=dev, dtype=torch.float32)
+    m = m[0] if m.dim() == 4 else m
+    assert m.dim() == 3 and m.shape[0] == 2, 'coord_2d must be (1,2,H,W) or (2,H,W) — one image per call'
+    m = m.contiguous()
+    return m.data_ptr(), int(m.shape[1]), int(m.shape[2])
+
+
+def roi_align_avg(input, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned=True):
+    """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned) forward
+    (``mr_roi_align_avg``).  input (N,C,H,W) f32 on the GPU, rois (K,5) [batch_idx, x1, y1, x2, y2] -> (K,C,oh,ow)."""
+    lib = _lib.load()
+    dev = input.device
+    if dev.type != 'cuda':
+        raise RuntimeError('monorun_amd.roi_align_avg runs on an MI355X only (no CPU fallback)')
+    oh, ow = (output_size, output_size) if isinstance(output_size, int) else tuple(int(v) for v in output_size)
+    x = input.detach().to(torch.float32).contiguous()
+    r = rois.detach().to(device=dev, dtype=torch.float32).contiguous()
+    N, C, H, W = x.shape
+    out = torch.empty(r.shape[0], C, oh, ow, device=dev, dtype=torch.float32)
+    if r.shape[0]:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_roi_align_avg(x.data_ptr(), r.data_ptr(), r.shape[0], C, H, W, oh, ow, float(spatial_scale), int(sampling_ratio),
+                                            int(bool(aligned)), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return out
+
+
 def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_agnostic=False,
                dim_means=DIM_MEANS, dim_stds=DIM_STDS, noc_means=NOC_MEANS, noc_stds=NOC_STDS,
                ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0,
-               std_scale=10, epnp_ransac_thres_ratio=0.2):
+               std_scale=10, epnp_ransac_thres_ratio=0.2, coord_2d=None):
     """Raw NOC-head output -> PnP-boundary maps, on the device, in one kernel.
 
     all_pred (B, 2*C*5, h, w) f32; labels (B,) int64; flip bool | (B,) bool; dim (B,3); dim_var (B,3)|None;
     rois (B,4) xyxy or (B,5) [batch_idx, x1, y1, x2, y2] (mmdet bbox2roi).
+    coord_2d: None (identity pixel grid: bin centres written analytically) or the image's (1,2,H,W)/(2,H,W) coordinate map
+    (loading.py:67-78 after resize/flip/pad), sampled with mmcv's exact RoIAlign rule (monorun_roi_head.py:521-523).
     Returns dict(coords_2d (B,2,h,w), coords_2d_istd (B,2,h,w), coords_3d (B,3,h,w), dims (B,3),
                  dims_var (B,3)|None, ransac_thr (B,)|None).
     """
@@ -98,7 +131,7 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
                 float(epnp_ransac_thres_ratio) if epnp_ransac_thres_ratio is not None else -1.0,
                 c2d.data_ptr(), istd.data_ptr(), c3d.data_ptr(), dims.data_ptr(),
                 dims_var.data_ptr() if dims_var is not None else None, thr.data_ptr() if thr is not None else None,
-                torch.cuda.current_stream(dev).cuda_stream))
+                *_coord_map_args(coord_2d, dev), torch.cuda.current_stream(dev).cuda_stream))
     return dict(coords_2d=c2d, coords_2d_istd=istd, coords_3d=c3d, dims=dims, dims_var=dims_var, ransac_thr=thr)
 
 
@@ -106,7 +139,7 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
                   dim_means=DIM_MEANS, dim_stds=DIM_STDS, noc_means=NOC_MEANS, noc_stds=NOC_STDS,
                   ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0, std_scale=10,
                   epnp_ransac_thres_ratio=0.2, allowed_border=200, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True,
-                  flags=0, with_diag=False):
+                  flags=0, with_diag=False, coord_2d=None):
     """Raw NOC-head output -> (ret_val, yaw, t_vec, pose_cov, inlier_mask, dims, dims_var[, diag]) in ONE launch
     (``mr_pnp_from_head_batched``): the decoded 2D/3D/istd maps only ever exist in the kernel's LDS tile."""
     lib = _lib.load()
@@ -146,7 +179,8 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
                 float(z_min), float(epnp_istd_thres), int(bool(inlier_opt_only)), int(flags),
                 valid.data_ptr(), pose.data_ptr(), cov.data_ptr(), tr.data_ptr(), mask.data_ptr(),
                 diag.data_ptr() if diag is not None else None, dims.data_ptr(),
-                dims_var.data_ptr() if dims_var is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+                dims_var.data_ptr() if dims_var is not None else None, *_coord_map_args(coord_2d, dev),
+                torch.cuda.current_stream(dev).cuda_stream))
     out = (valid.bool(), pose[:, :1], pose[:, 1:], cov, mask.bool(), dims, dims_var)
     return out + (diag,) if with_diag else out
 

@@ -390,3 +390,53 @@ def noc_cost_grad(pts2d, pts3d, wgt2d, logdim, logdim_wgt, K, x, clips, delta, f
                                  _p(logdim_wgt, c_dp), _p(K, c_dp), _p(x, c_dp), ctypes.c_int(pts2d.shape[0]), _p(clips, c_dp),
                                  ctypes.c_double(delta), _p(cost, c_dp), _p(g, c_dp), _p(H, c_dp))
     return bool(ok), float(cost[0]), g, H
+
+
+# ------------------------------------------------------------------ N3: RoIAlign (average pooling) ---
+def roi_align_avg(inp, rois, out_hw, spatial_scale=1.0, sampling_ratio=0, aligned=True):
+    """mmcv.ops.roi_align(input, rois, out_hw, spatial_scale, sampling_ratio, 'avg', aligned) forward, float32, operation
+    for operation as the published kernel (mmcv 1.2.1 roi_align_cuda_kernel.cuh; mmcv is third-party and absent from the
+    reference tree: parity with it is UNPINNED, the restatement is checked against closed forms in tests/).
+    inp (N,C,H,W), rois (K,5) [batch_idx, x1, y1, x2, y2] -> (K,C,oh,ow)."""
+    f = np.float32
+    inp = np.asarray(inp, f)
+    rois = np.asarray(rois, f)
+    N, C, H, W = inp.shape
+    oh, ow = out_hw
+    out = np.zeros((rois.shape[0], C, oh, ow), f)
+    ph = np.arange(oh, dtype=f)[:, None]
+    pw = np.arange(ow, dtype=f)[None, :]
+    for n in range(rois.shape[0]):
+        bi = int(rois[n, 0])
+        off = f(0.5) if aligned else f(0.0)
+        sw, sh = f(rois[n, 1] * f(spatial_scale)) - off, f(rois[n, 2] * f(spatial_scale)) - off
+        rw, rh = (f(rois[n, 3] * f(spatial_scale)) - off) - sw, (f(rois[n, 4] * f(spatial_scale)) - off) - sh
+        if not aligned:
+            rw, rh = max(rw, f(1.0)), max(rh, f(1.0))
+        bh, bw = f(rh / f(oh)), f(rw / f(ow))
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(f(rh / f(oh))))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(f(rw / f(ow))))
+        count = f(max(gh * gw, 1))
+        acc = np.zeros((C, oh, ow), f)
+        for iy in range(gh):
+            y = (sh + ph * bh) + f(f(f(iy) + f(0.5)) * bh) / f(gh)                  # (oh,1)
+            for ix in range(gw):
+                x = (sw + pw * bw) + f(f(f(ix) + f(0.5)) * bw) / f(gw)              # (1,ow)
+                yy = np.broadcast_to(y, (oh, ow)).astype(f).copy()
+                xx = np.broadcast_to(x, (oh, ow)).astype(f).copy()
+                dead = (yy < -1.0) | (yy > H) | (xx < -1.0) | (xx > W)
+                yy = np.where(yy <= 0, f(0), yy)
+                xx = np.where(xx <= 0, f(0), xx)
+                yl, xl = yy.astype(np.int32), xx.astype(np.int32)
+                top, right = yl >= H - 1, xl >= W - 1
+                yl = np.where(top, H - 1, yl); xl = np.where(right, W - 1, xl)
+                yh = np.where(top, H - 1, yl + 1); xh = np.where(right, W - 1, xl + 1)
+                yy = np.where(top, yl.astype(f), yy); xx = np.where(right, xl.astype(f), xx)
+                ly, lx = (yy - yl.astype(f)).astype(f), (xx - xl.astype(f)).astype(f)
+                hy, hx = (f(1.0) - ly).astype(f), (f(1.0) - lx).astype(f)
+                m = inp[bi]
+                v1, v2, v3, v4 = m[:, yl, xl], m[:, yl, xh], m[:, yh, xl], m[:, yh, xh]
+                val = (((hy * hx) * v1 + (hy * lx) * v2).astype(f) + (ly * hx) * v3).astype(f) + (ly * lx) * v4
+                acc = (acc + np.where(dead, f(0), val.astype(f))).astype(f)
+        out[n] = acc / count
+    return out
