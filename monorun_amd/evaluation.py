@@ -26,7 +26,8 @@ import torch
 from . import _lib
 
 __all__ = ['kitti_eval', 'kitti_eval_coco_style', 'eval_class', 'calculate_iou_partly', 'get_mAP', 'get_thresholds',
-           'do_eval', 'format_results', 'format_gt_anno', 'write_result_files', 'cam_t_vec_from_calib']
+           'do_eval', 'format_results', 'format_gt_anno', 'write_result_files', 'cam_t_vec_from_calib',
+           'open_calib_file', 'open_label_file', 'parse_ann_info', 'evaluate']
 
 _CLASS_NAMES = ('car', 'pedestrian', 'cyclist')                     # eval.py:29
 _MIN_HEIGHT = (40, 25, 25)
@@ -413,3 +414,74 @@ def write_result_files(results, filenames, result_dir):
              result['alpha'].reshape(-1, 1), result['bbox'], result['dimensions'][:, [1, 2, 0]], result['location'],
              result['rotation_y'].reshape(-1, 1), result['score'].reshape(-1, 1)), axis=1)
         np.savetxt(os.path.join(result_dir, stem + '.txt'), cols, delimiter=' ', fmt='%s')
+
+
+# ------------------------------------------------------------------------------------------------
+# KITTI files -> annotation infos, and the dataset-level `evaluate` (monorun/datasets/kitti3d_dataset.py)
+
+def open_calib_file(calib_file, cam=2):
+    """kitti3d_dataset.py:40-47: row `cam` (P0..P3) of a KITTI calib file as a (3,4) float32 projection matrix."""
+    assert 0 <= cam <= 3
+    with open(calib_file) as f:
+        row = f.readlines()[cam]
+    return np.array([float(v) for v in row.strip().split(' ')[1:]], dtype=np.float32).reshape((3, 4))
+
+
+def open_label_file(path):
+    """kitti3d_dataset.py:49-56: list of label rows [name, truncation, occlusion(int), alpha, x1, y1, x2, y2, h, w, l, x, y, z, ry]."""
+    rows = []
+    with open(path) as f:
+        for line in f:
+            parts = line.strip().split(' ')
+            if parts == ['']:
+                continue
+            rows.append([p if i == 0 else int(float(p)) if i == 2 else float(p) for i, p in enumerate(parts)])
+    return rows
+
+
+def parse_ann_info(label, calib, classes=('Car', 'Pedestrian', 'Cyclist')):
+    """kitti3d_dataset.py:116-178 (`_parse_ann_info`): the per-image annotation info.  Only objects of `classes` are kept
+    (plus DontCare boxes as `bboxes_ignore`); 3-D boxes are [l,h,w, x,y,z, ry]: `bboxes_3d` in camera space (shifted by
+    cam_t_vec), `bboxes_3d_eval` in the label file's reference space.  label=None (test mode): calibration only."""
+    K, cam_t_vec = cam_t_vec_from_calib(calib)
+    ann = dict(cam_intrinsic=K.astype(np.float32), cam_t_vec=cam_t_vec.astype(np.float32))
+    if label is None:
+        return ann
+    ids, boxes, labels, ignore, trunc, occ, alpha, b3 = [], [], [], [], [], [], [], []
+    for object_id, inst in enumerate(label):
+        if inst[0] in classes:
+            ids.append(object_id); labels.append(classes.index(inst[0]))
+            trunc.append(inst[1]); occ.append(inst[2]); alpha.append(inst[3]); boxes.append(inst[4:8]); b3.append(inst[8:15])
+        elif inst[0].lower() == 'dontcare':
+            ignore.append(inst[4:8])
+    boxes = np.array(boxes, dtype=np.float32).reshape(-1, 4)
+    b3 = np.array(b3, dtype=np.float32).reshape(-1, 7)
+    b3[:, [0, 1, 2]] = b3[:, [2, 0, 1]]                              # hwl -> lhw
+    b3_eval = b3.copy()
+    b3[:, 3:6] += ann['cam_t_vec']
+    ann.update(object_ids=np.array(ids, dtype=np.int64), bboxes=boxes, labels=np.array(labels, dtype=np.int64),
+               bboxes_ignore=np.array(ignore, dtype=np.float32).reshape(-1, 4), truncation=trunc, occlusion=occ, alpha=alpha,
+               bboxes_3d=b3, bboxes_3d_eval=b3_eval)
+    return ann
+
+
+def evaluate(results, gt_ann_infos, classes=('Car', 'Pedestrian', 'Cyclist'), metric=('bbox', 'bev', '3d'), filenames=None,
+             result_dir=None, summary_file=None, print_summary=False, use_r40=True):
+    """`KITTI3DDataset.evaluate` (kitti3d_dataset.py:195-228): pipeline results -> KITTI detection annotations (+ result
+    files under result_dir/data) -> kitti_eval against the labels.  Returns (ap_dict, result text, detection annos);
+    infos without labels (test mode) give an empty dict."""
+    det_annos = format_results(results, gt_ann_infos, classes)
+    if result_dir is not None:
+        if not os.path.exists(result_dir):
+            os.mkdir(result_dir)
+        write_result_files(det_annos, filenames, os.path.join(result_dir, 'data'))
+    if not all('bboxes' in info for info in gt_ann_infos):
+        return dict(), '', det_annos
+    gt_annos = [format_gt_anno(info, classes) for info in gt_ann_infos]
+    text, ap = kitti_eval(gt_annos, det_annos, list(classes), eval_types=list(metric), criteria='R40' if use_r40 else 'R11')
+    if print_summary:
+        print('\n' + text)
+    if summary_file is not None:
+        with open(summary_file, 'w') as f:
+            f.write(text)
+    return ap, text, det_annos

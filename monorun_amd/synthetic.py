@@ -16,6 +16,8 @@ IMG_W, IMG_H = 1242, 375
 # multiclass_norm_dim_coder.py:8-15 — (l, h, w) mean / std per class (car, pedestrian, cyclist)
 DIM_MEANS = np.array([(3.89, 1.53, 1.62), (0.82, 1.78, 0.63), (1.77, 1.72, 0.57)])
 DIM_STDS = np.array([(0.44, 0.14, 0.11), (0.25, 0.13, 0.12), (0.15, 0.10, 0.14)])
+NOC_MEANS = (-0.1, -0.5, 0.0)            # noc_coder.py:12-13
+NOC_STDS = (0.35, 0.23, 0.34)
 
 
 def cube_config1(n_points=64, seed=0):
@@ -150,7 +152,6 @@ def pnp_boundary(batch, allowed_border=200, ransac_ratio=0.2, std_scale=10.0, pl
 # exercised on synthetic label / detection sets in the exact dict format the reference's evaluator reads
 # (kitti3d_dataset.py:230-305: name, truncated, occluded, alpha, bbox, dimensions [l,h,w], location
 # [x, y(bottom), z] in the camera frame, rotation_y, score).
-KITTI_K = np.array([[707.0912, 0.0, 601.8873], [0.0, 707.0912, 183.1104], [0.0, 0.0, 1.0]])
 _KITTI_DIMS = {  # mean l, h, w
     'Car': (3.89, 1.53, 1.62), 'Van': (5.08, 2.21, 1.90), 'Pedestrian': (0.84, 1.76, 0.66),
     'Person_sitting': (0.80, 1.27, 0.59), 'Cyclist': (1.76, 1.74, 0.60),
@@ -270,3 +271,24 @@ def unpack_kitti_annos(z, prefix):
             a[k] = z[prefix + k][s].copy()
         annos.append(a)
     return annos
+
+
+# ---------------------------------------------------------------------------------------------------
+# Synthetic raw NOC-head outputs (the inverse of the decode chain) — lets the whole post-head tail
+# (decode -> PnP -> 3-D boxes -> KITTI files -> evaluator) run end to end without the CNN or a dataset.
+def encode_head_outputs(batch, num_classes=3, seed=0):
+    """make_batch() maps -> (all_pred (B, 2*C*5, h, w) float32, dim (B,3) normalised dimensions).
+    Branch 0 (no flip) of the object's class carries noc = (X / dims - mu_noc) / sigma_noc and the pixel log-std;
+    every other channel is noise, so a wrong channel pick shows up as a wrong pose."""
+    rng = np.random.default_rng(seed)
+    c3d, ls, labels, dims = batch['coords_3d'], batch['logstd'], batch['labels'], batch['dims']
+    B, _, h, w = c3d.shape
+    C = num_classes
+    all_pred = rng.normal(0, 1, (B, 2 * C * 5, h, w)).astype(np.float32)
+    noc = (c3d / dims[:, :, None, None] - np.asarray(NOC_MEANS, np.float32)[None, :, None, None]) / np.asarray(NOC_STDS, np.float32)[None, :, None, None]
+    for b in range(B):
+        c = int(labels[b])
+        all_pred[b, 3 * c:3 * c + 3] = noc[b]
+        all_pred[b, 3 * C + 2 * c:3 * C + 2 * c + 2] = ls[b]
+    dim = ((dims - DIM_MEANS[labels]) / DIM_STDS[labels]).astype(np.float32)
+    return all_pred, dim

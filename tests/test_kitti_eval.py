@@ -199,3 +199,53 @@ def test_gpu_eval_edge_cases():
     want = ke.get_map(ke.eval_class(gts, dts, [0], [0, 1, 2], 2, mo10)['precision'], 'R40').mean(-1)
     line = [l for l in coco.split('\n') if l.startswith('3d ')][0]
     assert line == '3d   AP:{:.2f}, {:.2f}, {:.2f}'.format(*want[0])
+
+
+def test_kitti_file_io_roundtrip(tmp_path):
+    """open_label_file / open_calib_file / parse_ann_info (kitti3d_dataset.py:40-56,116-178) on files written in the KITTI
+    format, and result files read back as labels."""
+    from monorun_amd import evaluation as ev
+    P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]])
+    (tmp_path / 'c.txt').write_text(''.join(f'P{i}: ' + ' '.join(f'{v:.12e}' for v in (P2 + i).reshape(-1)) + '\n' for i in range(4)))
+    calib = ev.open_calib_file(str(tmp_path / 'c.txt'), 2)
+    np.testing.assert_allclose(calib, P2 + 2, rtol=1e-6)
+    (tmp_path / 'l.txt').write_text(
+        'Car 0.00 0 -1.58 587.01 173.33 614.12 200.12 1.65 1.67 3.64 -0.65 1.71 46.70 -1.59\n'
+        'Van 0.10 1 1.00 10.0 20.0 30.0 40.0 2.0 1.9 5.0 1.0 1.5 20.0 0.5\n'
+        'DontCare -1 -1 -10 503.89 169.71 590.61 190.13 -1 -1 -1 -1000 -1000 -1000 -10\n'
+        'Cyclist 0.25 2 0.30 100.0 120.0 150.0 200.0 1.70 0.60 1.80 -5.0 1.6 12.0 0.1\n')
+    label = ev.open_label_file(str(tmp_path / 'l.txt'))
+    assert len(label) == 4 and label[0][0] == 'Car' and isinstance(label[0][2], int) and label[3][2] == 2
+    ann = ev.parse_ann_info(label, calib)
+    assert ann['labels'].tolist() == [0, 2] and ann['object_ids'].tolist() == [0, 3]        # the Van is dropped, DontCare kept apart
+    assert ann['bboxes_ignore'].shape == (1, 4) and ann['bboxes'].shape == (2, 4)
+    np.testing.assert_allclose(ann['bboxes_3d_eval'][0], [3.64, 1.65, 1.67, -0.65, 1.71, 46.70, -1.59], rtol=1e-6)   # lhw xyz ry
+    np.testing.assert_allclose(ann['bboxes_3d'][0, 3:6] - ann['bboxes_3d_eval'][0, 3:6], ann['cam_t_vec'], rtol=1e-5)
+    np.testing.assert_allclose(ann['cam_intrinsic'] @ ann['cam_t_vec'], calib[:, 3], rtol=1e-4, atol=1e-4)
+    assert set(ev.parse_ann_info(None, calib)) == {'cam_intrinsic', 'cam_t_vec'}               # test mode
+    gt = ev.format_gt_anno(ann, ('Car', 'Pedestrian', 'Cyclist'))
+    assert gt['name'] == ['Car', 'Cyclist', 'DontCare'] and gt['occluded'].tolist() == [0, 2, -1]
+    # result files are label files with a score column
+    det = dict(name=np.array(['Car']), truncated=np.array([-1], np.int8), occluded=np.array([-1], np.int8), alpha=np.array([0.5], np.float32),
+               bbox=np.array([[1, 2, 3, 4]], np.float32), dimensions=np.array([[3.9, 1.5, 1.6]], np.float32),
+               location=np.array([[1.0, 1.6, 20.0]], np.float32), rotation_y=np.array([0.2], np.float32), score=np.array([0.9], np.float32))
+    ev.write_result_files([det], ['000001.png'], str(tmp_path / 'data'))
+    back = ev.open_label_file(str(tmp_path / 'data' / '000001.txt'))
+    np.testing.assert_allclose(back[0][8:11], [1.5, 1.6, 3.9], rtol=1e-6)                    # h w l
+    assert back[0][0] == 'Car' and abs(back[0][15] - 0.9) < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_end_to_end_harness_synthetic():
+    """tools/kitti_val.py --synthetic: label/calib files + synthetic raw head outputs -> fused decode+PnP -> 3-D boxes ->
+    KITTI result files -> evaluator.  Small 3-D noise, so the recovered boxes must score a high AP."""
+    import subprocess, sys, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'kitti_val.py'), '--synthetic', '40'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout
+    block = text[text.index('Car AP@0.70, 0.50, 0.50'):]
+    ap3d = [float(v) for v in re.search(r'3d   AP:([\d.]+), ([\d.]+), ([\d.]+)', block).groups()]
+    bev = [float(v) for v in re.search(r'bev  AP:([\d.]+), ([\d.]+), ([\d.]+)', block).groups()]
+    assert min(ap3d[1:]) > 80 and min(bev[1:]) > 80, text
+    assert '40 images, 240 objects' in text
