@@ -15,7 +15,7 @@ def planar_rep(a, dt):
 for dt, name, bps in ((torch.float16, 'fp16', 3136 * 7 * 2 + 56 + 85 + 3136), (torch.float32, 'fp32', 3136 * 7 * 4 + 56 + 85 + 3136)):
     X2, W, X3 = planar_rep(x2d, dt), planar_rep(istd, dt), planar_rep(x3d, dt)
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
-    for wpo in (4, 8):
+    for wpo in (0, 2, 4, 8):
         L = PnPLaunch(X2, W, X3, t(K), t(ur), t(vr), 0.5, 0.6, t(thr).repeat(rep), True, flags=(wpo << 8))
         for _ in range(2): L.run()
         torch.cuda.synchronize()
