@@ -140,6 +140,9 @@ int mr_noc_decode_batched(
  * output, constants) followed by those of mr_pnp_uncert_batched (camera, ranges, options, outputs); results
  * are identical, bit for bit, to calling the two entry points in sequence.  dims / dims_var (B,3): optional
  * decoded dimensions for the consumers.  ransac_thres_ratio < 0 disables the consensus step.
+ * cov_calib (optional): the pose head's calibrated covariance (s s^T) * cov with s = exp(cov_calib_logscale)
+ * (uncert_prop_pnp_optimizer.py:96-97), times (cov_corr_sd / ||t||)^2 when cov_corr_sd > 0 (cov_correction,
+ * distance_invar_proj_error_coder.py:62-63, monorun_roi_head.py:530-534) — written by the same launch.
  */
 int mr_pnp_from_head_batched(
     const float *all_pred, const int64_t *labels, const uint8_t *flip,
@@ -151,7 +154,9 @@ int mr_pnp_from_head_batched(
     const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
-    float *dims, float *dims_var, const float *coord_2d_map, int map_h, int map_w, void *stream);
+    float *dims, float *dims_var, const float *coord_2d_map, int map_h, int map_w,
+    const float *cov_calib_logscale /* (4) or NULL */, float cov_corr_sd /* <= 0: no distance correction */,
+    float *cov_calib /* (B,16) or NULL */, void *stream);
 
 /*
  * N3: RoIAlign forward, average pooling — mmcv.ops.roi_align(input, rois, (out_h,out_w), spatial_scale, sampling_ratio,

@@ -84,7 +84,7 @@ def load():
         vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
         vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
         vp, i32, vp, vp, i32, f32, f32, i32, i32,
-        vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+        vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, vp, vp]
     lib.mr_roi_align_avg.restype = i32
     lib.mr_roi_align_avg.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp]
     for name in ('pnp_noc_uncert', 'pnp_noc_cov_uncert'):

@@ -205,6 +205,7 @@ struct PnpArgs {
     uint8_t *valid; float *pose; float *cov; float *tr; uint8_t *mask; float *diag;
     double *pose64, *cov64, *tr64;            // legacy per-object ABI outputs (nullable)
     unsigned long long *stamps;               // debug: (B,24) s_memtime stamps (nullable)
+    const float *calib_logscale; float corr_sd; float *cov_calib;   // optional fused R8/R13 epilogue: calibrated + distance-corrected covariance
     int from_head;                            // 1: the tile is decoded in-kernel from the raw NOC-head output (`dec`)
     DecodeArgs dec;
     PairwisePlan plan;
@@ -569,7 +570,8 @@ int mr_pnp_from_head_batched(
     const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag,
-    float *dims, float *dims_var, const float *coord_2d_map, int map_h, int map_w, void *stream) {
+    float *dims, float *dims_var, const float *coord_2d_map, int map_h, int map_w,
+    const float *cov_calib_logscale, float cov_corr_sd, float *cov_calib, void *stream) {
     const int P = h * w;
     if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
     if (coord_2d_map && (map_h < 1 || map_w < 1)) return MR_ERR_BAD_ARGUMENT;
@@ -583,6 +585,8 @@ int mr_pnp_from_head_batched(
     if (rc != MR_OK) return rc;
     a.dec.dims = dims; a.dec.dims_var = dims_var;
     a.dec.map2d = coord_2d_map; a.dec.map_h = map_h; a.dec.map_w = map_w;
+    if (cov_calib && (!cov_calib_logscale || (flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
+    a.calib_logscale = cov_calib_logscale; a.corr_sd = cov_corr_sd; a.cov_calib = cov_calib;
     a.from_head = 1;
     // the tile is built channel-planar, exactly the layout (and hence numpy summation order) the reference's head produces
     a.s2[0] = 2LL * P; a.s2[1] = 1; a.s2[2] = P; a.sw[0] = 2LL * P; a.sw[1] = 1; a.sw[2] = P; a.s3[0] = 3LL * P; a.s3[1] = 1; a.s3[2] = P;

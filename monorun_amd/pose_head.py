@@ -27,16 +27,30 @@ DIM_STDS = ((0.44, 0.14, 0.11), (0.25, 0.13, 0.12), (0.15, 0.10, 0.14))
 
 
 _CONST_CACHE = {}
+_CONST_BY_ID = {}
 
 
 def _const(values, dev):
-    """Small constant tensors (coder means/stds, clip ranges) live on the device once per (device, value)."""
-    key = (str(dev), tuple(np.asarray(values, np.float32).ravel().tolist()), np.asarray(values).shape)
+    """Small constant tensors (coder means/stds, clip ranges) live on the device once per (device, value).  The same
+    Python object (the module-level defaults, a config tuple) is recognised by identity without being re-hashed."""
+    ik = (id(values), dev)
+    hit = _CONST_BY_ID.get(ik)
+    if hit is not None and hit[0] is values:
+        return hit[1]
+    arr = np.asarray(values, np.float32)
+    key = (str(dev), arr.tobytes(), arr.shape)
     t = _CONST_CACHE.get(key)
     if t is None:
-        t = torch.tensor(np.asarray(values, np.float32), device=dev).contiguous()
+        t = torch.tensor(arr, device=dev).contiguous()
         _CONST_CACHE[key] = t
+    if not isinstance(values, np.ndarray) or not values.flags.writeable:      # a mutable array may change under the same id
+        if len(_CONST_BY_ID) > 256:
+            _CONST_BY_ID.clear()
+        _CONST_BY_ID[ik] = (values, t)
     return t
+
+
+_RANGE_CACHE = {}
 
 
 def _clip_ranges(img_shapes, allowed_border, dev):
@@ -47,9 +61,15 @@ def _clip_ranges(img_shapes, allowed_border, dev):
         ur[:, 1] = sh[:, 1] + allowed_border; vr[:, 1] = sh[:, 0] + allowed_border
         return ur, vr
     sh = np.asarray(img_shapes.cpu() if torch.is_tensor(img_shapes) else img_shapes, np.float32).reshape(-1, 2)
-    ur = np.stack([np.full(len(sh), -float(allowed_border), np.float32), sh[:, 1] + allowed_border], 1)
-    vr = np.stack([np.full(len(sh), -float(allowed_border), np.float32), sh[:, 0] + allowed_border], 1)
-    return _const(ur, dev), _const(vr, dev)
+    key = (sh.tobytes(), float(allowed_border), dev)
+    hit = _RANGE_CACHE.get(key)
+    if hit is None:
+        ur = np.stack([np.full(len(sh), -float(allowed_border), np.float32), sh[:, 1] + allowed_border], 1)
+        vr = np.stack([np.full(len(sh), -float(allowed_border), np.float32), sh[:, 0] + allowed_border], 1)
+        if len(_RANGE_CACHE) > 256:
+            _RANGE_CACHE.clear()
+        hit = _RANGE_CACHE[key] = (torch.tensor(ur, device=dev), torch.tensor(vr, device=dev))
+    return hit
 
 
 def _coord_map_args(coord_2d, dev):
@@ -139,9 +159,11 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
                   dim_means=DIM_MEANS, dim_stds=DIM_STDS, noc_means=NOC_MEANS, noc_stds=NOC_STDS,
                   ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0, std_scale=10,
                   epnp_ransac_thres_ratio=0.2, allowed_border=200, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True,
-                  flags=0, with_diag=False, coord_2d=None):
-    """Raw NOC-head output -> (ret_val, yaw, t_vec, pose_cov, inlier_mask, dims, dims_var[, diag]) in ONE launch
-    (``mr_pnp_from_head_batched``): the decoded 2D/3D/istd maps only ever exist in the kernel's LDS tile."""
+                  flags=0, with_diag=False, coord_2d=None, cov_calib_logscale=None, cov_correction_sd=0.0):
+    """Raw NOC-head output -> (ret_val, yaw, t_vec, pose_cov, inlier_mask, dims, dims_var[, diag][, pose_cov_calib]) in ONE
+    launch (``mr_pnp_from_head_batched``): the decoded 2D/3D/istd maps only ever exist in the kernel's LDS tile.
+    cov_calib_logscale (4,): also return the calibrated covariance (s s^T) * cov (uncert_prop_pnp_optimizer.py:96-97),
+    multiplied by (cov_correction_sd / ||t||)^2 when cov_correction_sd > 0 (monorun_roi_head.py:530-534)."""
     lib = _lib.load()
     dev = all_pred.device
     if dev.type != 'cuda':
@@ -149,26 +171,42 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
     B, ch, h, w = all_pred.shape
     Cn = 1 if class_agnostic else num_classes
     assert ch == 2 * Cn * 5, f'all_pred has {ch} channels, expected {2 * Cn * 5}'
-    f32 = dict(device=dev, dtype=torch.float32)
-    ap = all_pred.detach().to(**f32).contiguous()
-    lab = labels.detach().to(device=dev, dtype=torch.int64).contiguous()
-    fl = torch.full((B,), int(flip), device=dev, dtype=torch.uint8) if isinstance(flip, bool) \
-        else torch.as_tensor(flip, device=dev).to(torch.uint8).contiguous()
-    dm = dim.detach().to(**f32).contiguous()
-    dv = dim_var.detach().to(**f32).contiguous() if dim_var is not None else None
-    r = rois.detach().to(**f32)
-    r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
+    f32t = torch.float32
+
+    def prep(x, dt=f32t):                            # no-op for the tensors the pipeline already holds
+        x = x.detach()
+        if x.dtype != dt or x.device != dev:
+            x = x.to(device=dev, dtype=dt)
+        return x if x.is_contiguous() else x.contiguous()
+    ap, lab, dm = prep(all_pred), prep(labels, torch.int64), prep(dim)
+    fl = _flip_flags(flip, B, dev)
+    dv = prep(dim_var) if dim_var is not None else None
+    r = prep(rois)
+    if r.shape[1] == 5:
+        r = r[:, 1:5].contiguous()
     mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
-    cam = cam_intrinsic.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    cam = prep(cam_intrinsic).reshape(-1, 3, 3)
     ur, vr = _clip_ranges(img_shapes, allowed_border, dev)
     P = h * w
-    valid = torch.empty(B, device=dev, dtype=torch.uint8)
-    pose = torch.empty(B, 4, **f32); cov = torch.empty(B, 4, 4, **f32); tr = torch.empty(B, **f32)
-    mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
-    diag = torch.empty(B, 4, **f32) if with_diag else None
-    dims = torch.empty(B, 3, **f32)
-    dims_var = torch.empty(B, 3, **f32) if dv is not None else None
+    calib = cov_calib_logscale is not None
+    # one float buffer and one byte buffer hold every output (two allocations per call)
+    nf = 4 + 16 + 1 + 3 + (3 if dv is not None else 0) + (4 if with_diag else 0) + (16 if calib else 0)
+    fbuf = torch.empty(max(B, 1) * nf, device=dev, dtype=f32t)
+    bbuf = torch.empty(max(B, 1) * (1 + P), device=dev, dtype=torch.uint8)
+    off = [0]
+
+    def take(n):
+        v = fbuf[off[0]:off[0] + B * n]
+        off[0] += B * n
+        return v
+    pose, cov, tr, dims = take(4).view(B, 4), take(16).view(B, 4, 4), take(1), take(3).view(B, 3)
+    dims_var = take(3).view(B, 3) if dv is not None else None
+    diag = take(4).view(B, 4) if with_diag else None
+    cov_calib = take(16).view(B, 4, 4) if calib else None
+    valid, mask = bbuf[:B], bbuf[B:B + B * P].view(B, P)
+    ls = prep(cov_calib_logscale) if calib else None
     if B > 0:
+        mp, mh, mw = _coord_map_args(coord_2d, dev)
         with torch.cuda.device(dev):
             _lib.check(lib.mr_pnp_from_head_batched(
                 ap.data_ptr(), lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
@@ -179,10 +217,32 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
                 float(z_min), float(epnp_istd_thres), int(bool(inlier_opt_only)), int(flags),
                 valid.data_ptr(), pose.data_ptr(), cov.data_ptr(), tr.data_ptr(), mask.data_ptr(),
                 diag.data_ptr() if diag is not None else None, dims.data_ptr(),
-                dims_var.data_ptr() if dims_var is not None else None, *_coord_map_args(coord_2d, dev),
+                dims_var.data_ptr() if dims_var is not None else None, mp, mh, mw,
+                ls.data_ptr() if calib else None, float(cov_correction_sd), cov_calib.data_ptr() if calib else None,
                 torch.cuda.current_stream(dev).cuda_stream))
-    out = (valid.bool(), pose[:, :1], pose[:, 1:], cov, mask.bool(), dims, dims_var)
-    return out + (diag,) if with_diag else out
+    out = (valid.view(torch.bool), pose[:, :1], pose[:, 1:], cov, mask.view(torch.bool), dims, dims_var)
+    if with_diag:
+        out = out + (diag,)
+    if calib:
+        out = out + (cov_calib,)
+    return out
+
+
+_FLIP_CACHE = {}
+
+
+def _flip_flags(flip, B, dev):
+    """(B,) uint8 flip flags; the usual per-image bool becomes a cached constant tensor."""
+    if isinstance(flip, (bool, np.bool_)):
+        key = (str(dev), bool(flip), B)
+        t = _FLIP_CACHE.get(key)
+        if t is None:
+            if len(_FLIP_CACHE) > 64:
+                _FLIP_CACHE.clear()
+            t = torch.full((max(B, 1),), int(flip), device=dev, dtype=torch.uint8)
+            _FLIP_CACHE[key] = t
+        return t
+    return torch.as_tensor(flip, device=dev).to(torch.uint8).contiguous()
 
 
 def _planar_view(x):
@@ -265,11 +325,14 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
     the decoded maps are materialised) — both give bit-identical results."""
     if fused:
         p = pose_head.pnp
-        ret_val, yaw, t_vec, cov, _, dims, dims_var = pnp_from_head(
+        sd = decode_kw.get('ref_length', 1.6) * decode_kw.get('ref_focal_y', 722) * decode_kw.get('target_std', 0.15)
+        ret_val, yaw, t_vec, cov, _, dims, dims_var, cov_calib = pnp_from_head(
             all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape, std_scale=pose_head.std_scale,
             epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, allowed_border=pose_head.allowed_border,
-            z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, inlier_opt_only=p.inlier_opt_only, **decode_kw)
-        cov_calib = pose_head._calibrate(cov)
+            z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, inlier_opt_only=p.inlier_opt_only,
+            cov_calib_logscale=pose_head.cov_calib_logscale, cov_correction_sd=sd if apply_cov_correction else 0.0, **decode_kw)
+        return dict(ret_val=ret_val, yaw_pred=yaw, t_vec_pred=t_vec, pose_cov_pred=cov, pose_cov_calib=cov_calib,
+                    dimensions_pred=dims, dimensions_var=dims_var)      # calibration + distance correction done by the kernel
     else:
         dec = noc_decode(all_pred, labels, flip, dim, dim_var, rois, std_scale=pose_head.std_scale,
                          epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, **decode_kw)

@@ -120,9 +120,11 @@ def test_tail_end_to_end_two_launches(dev, orc):
         res = pose_from_head(head, t(all_pred), t(labels), t(flip), t(dim), t(dim_var), t(b['rois']), t(b['K']), b['img_shape'])
         res2 = pose_from_head(head, t(all_pred), t(labels), t(flip), t(dim), t(dim_var), t(b['rois']), t(b['K']), b['img_shape'], fused=False)
     torch.cuda.synchronize()
-    # ONE fused launch == K2 followed by the PnP kernel, bit for bit
-    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'dimensions_pred', 'dimensions_var'):
+    # ONE fused launch == K2 followed by the PnP kernel, bit for bit (the calibrated covariance comes from the kernel's
+    # epilogue in the fused path and from torch ops in the other: same float32 formula, ulp-level agreement)
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'dimensions_pred', 'dimensions_var'):
         assert torch.equal(res[k], res2[k]), k
+    torch.testing.assert_close(res['pose_cov_calib'][res['ret_val']], res2['pose_cov_calib'][res2['ret_val']], rtol=2e-6, atol=0)
     assert np.array_equal(res['ret_val'].cpu().numpy(), ref[0])
     ok = ref[0]
     # istd goes through exp/log (few-ulp differences) before the bit-exact-thresholded mask, so compare poses, not masks
@@ -159,3 +161,29 @@ def test_fused_head_to_pose_matches_two_launches_everywhere(dev, g3):
         for a, b_ in zip(out[:5], ref):
             assert torch.equal(a, b_)
         assert torch.equal(out[5], dec['dims']) and (dv is None or torch.equal(out[6], dec['dims_var']))
+
+
+@pytest.mark.gpu
+def test_fused_calibration_and_distance_correction(dev, g3):
+    """The kernel's optional epilogue = UncertPropPnPOptimizer._calibrate (uncert_prop_pnp_optimizer.py:96-97) followed by
+    cov_correction (monorun_roi_head.py:530-534) done with torch ops on the same covariance."""
+    from monorun_amd import pose_head as ph
+    rng = np.random.default_rng(9)
+    B = g3['all_pred'].shape[0]
+    rois = np.stack([rng.uniform(100, 900, B), rng.uniform(50, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(30, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    K = t(syn.KITTI_K[None].astype(np.float32))
+    head = ph.UncertPropPnPOptimizer().to(dev)
+    with torch.no_grad():
+        head.cov_calib_logscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.45]))
+    args = (t(g3['all_pred']), t(g3['labels']), t(g3['flip']), t(g3['dim']), t(g3['dim_var']), t(rois), K, (375, 1242))
+    for corr in (True, False):
+        with torch.no_grad():
+            a = ph.pose_from_head(head, *args, apply_cov_correction=corr, fused=True)
+            b = ph.pose_from_head(head, *args, apply_cov_correction=corr, fused=False)
+        for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'dimensions_pred', 'dimensions_var'):
+            assert torch.equal(a[k], b[k]), k
+        assert a['ret_val'].dtype == torch.bool and a['pose_cov_calib'].shape == (B, 4, 4)
+        ok = a['ret_val']
+        torch.testing.assert_close(a['pose_cov_calib'][ok], b['pose_cov_calib'][ok], rtol=2e-6, atol=0)

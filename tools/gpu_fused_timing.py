@@ -1,6 +1,7 @@
 """Head output -> pose: one fused launch vs K2 + PnP (development aid)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time
 import numpy as np, torch
 from monorun_amd import synthetic as syn
 from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
@@ -27,7 +28,7 @@ for B in (100, 1024):
             for _ in range(5): pose_from_head(head, *args, fused=fused)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(); c0 = time.perf_counter()
             for _ in range(30): r = pose_from_head(head, *args, fused=fused)
-            e1.record(); torch.cuda.synchronize()
-        print(f'B={B} fused={fused}: {e0.elapsed_time(e1)/30*1e3:.1f} us per head->pose call (includes the torch glue ops), valid {r["ret_val"].float().mean().item():.3f}')
+            c1 = time.perf_counter(); e1.record(); torch.cuda.synchronize()
+        print(f'B={B} fused={fused}: {e0.elapsed_time(e1)/30*1e3:.1f} us per head->pose call (includes the torch glue ops; host-side issue time {(c1-c0)/30*1e6:.1f} us), valid {r["ret_val"].float().mean().item():.3f}')
