@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, 'csrc', 'monorun_pnp.hip')
 INCLUDE = os.path.join(_ROOT, 'include')
-SO = os.path.join(_HERE, 'libmonorun_pnp.so')
+SO = os.environ.get('MR_PNP_SO') or os.path.join(_HERE, 'libmonorun_pnp.so')     # MR_PNP_SO: A/B-test another build of the library
 
 MR_F32, MR_F16, MR_F64 = 0, 1, 2
 MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
