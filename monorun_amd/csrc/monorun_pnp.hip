@@ -345,7 +345,7 @@ size_t lds_bytes(const PnpArgs &a, int wpo) {
     n += sizeof(int) * wpo * kHyp;
     n += sizeof(float) * (2 * a.nla * 8 + 4 * a.nla + 4);
     n += (size_t)2 * a.tile_bytes2 + a.tile_bytes3;
-    n += sizeof(uint16_t) * ((a.P + 7) & ~7);
+    n += 2 * sizeof(uint16_t) * ((a.P + 7) & ~7);        // candidate list + final inlier list
     n += a.P;
     return (n + 15) & ~(size_t)15;
 }
