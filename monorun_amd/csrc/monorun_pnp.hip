@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) nms_bev_kernel(const float *boxes, const 
 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
-    n += sizeof(double) * 2 * wpo * kRedN;
+    n += sizeof(double) * (2 * wpo * kRedN + 8);          // reduction scratch + leader/follower message
     n += (sizeof(unsigned long long) + sizeof(int)) * a.nca;
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
@@ -440,11 +440,11 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
 int pick_wpo(int B, int P, int flags) {
     int w = (flags & MR_WAVES_MASK) >> MR_WAVES_SHIFT;
     if (w) return w;
-    // The kernel is built for 3 resident waves per SIMD (<= 168 VGPRs) -> 3072 waves on 256 CUs x 4 SIMDs; a lone
-    // wave issues only ~1 VALU instruction per 7 cycles, so small batches are split over more wavefronts per
-    // object (measured on MI355X: B = 1024 is fastest at 4 waves/object, B = 8192 at 2).
+    // fp32 variants hold 4 resident waves per SIMD (<= 128 VGPRs) -> 4096 waves on 256 CUs x 4 SIMDs.  More waves per
+    // object shorten an object's latency chain (what bounds small batches), fewer waves cost fewer instructions per object
+    // (what bounds large ones).  Measured on MI355X, P = 784: 4 waves/object wins up to B = 2048, 2 from B = 4096.
     w = 1;
-    while (w < 4 && (long long)B * w * 2 <= 4096 && P >= 64 * w * 2) w *= 2;      // small batches: fill the SIMDs
+    while (w < 4 && (long long)B * w * 2 <= 8192 && P >= 64 * w * 2) w *= 2;      // small batches: fill the SIMDs
     int wp = 1;
     while (wp < 4 && P > 64 * wp * 8) wp *= 2;                                     // large tiles: <= ~8 points per lane
     if (wp > w) w = wp;                                                            // (P = 784 -> 2, P = 3136 -> 4)
