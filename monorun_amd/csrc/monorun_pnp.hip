@@ -340,10 +340,10 @@ __global__ void __launch_bounds__(256) nms_bev_kernel(const float *boxes, const 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
     n += sizeof(double) * (2 * wpo * kRedN + 8);          // reduction scratch + leader/follower message
-    n += (sizeof(unsigned long long) + sizeof(int)) * a.nca;
+    n += sizeof(unsigned long long) * a.nca;
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
-    n += sizeof(float) * (2 * a.nla * 8 + 4 * a.nla + 4);
+    n += sizeof(float) * (4 * a.nla + 4);
     n += (size_t)2 * a.tile_bytes2 + a.tile_bytes3;
     n += 2 * sizeof(uint16_t) * ((a.P + 7) & ~7);        // candidate list + final inlier list
     n += a.P;
