@@ -359,3 +359,35 @@ def test_side_stream_misaligned_and_strided_inputs(dev, orc, batch64):
     ref16 = orc.u2d_pnp(pl(h2.astype(np.float32)), pl(hw.astype(np.float32)), pl(h3.astype(np.float32)), Kc, ur, vr, 0.5, 0.6, thr8, True,
                         return_diag=True)
     _cmp(_run(dev, h2, hw, h3, Kc, ur, vr, thr8), ref16, 'fp16 odd sizes')
+
+
+@pytest.mark.gpu
+def test_adversarial_inputs_terminate_and_match_oracle_validity(dev, orc):
+    """Degenerate / non-finite inputs (coincident points, NaN and Inf correspondences, zero or negative weights, overflow,
+    garbage geometry, zero consensus threshold): every launch terminates, no non-finite pose is reported valid, and the
+    valid flags equal the oracle's — also exercises the leader/follower exits of the LM (evaluation failure, refit failure)."""
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    rng = np.random.default_rng(11)
+    for trial in range(16):
+        B = int(rng.choice([1, 3, 64])); hw = int(rng.choice([2, 3, 10, 28]))
+        b = syn.make_batch(B=B, hw=hw, seed=int(rng.integers(1 << 30)))
+        x2d, istd, x3d, K, ur, vr, thr = [np.array(a, copy=True) for a in syn.pnp_boundary(b, planar=bool(rng.integers(2)))]
+        P = x2d.shape[1]
+        sel = rng.uniform(size=B) < 0.5
+        mode = trial % 8
+        if mode == 0: x3d[sel] = 0.0
+        elif mode == 1: x2d[sel, rng.integers(P)] = np.nan
+        elif mode == 2: istd[sel] = 0.0
+        elif mode == 3: x3d[sel] *= 1e20
+        elif mode == 4: istd[sel] = -istd[sel]
+        elif mode == 5: x3d[sel] = rng.normal(0, 1, x3d[sel].shape).astype(np.float32)
+        elif mode == 6: thr[sel] = 0.0
+        else: x2d[sel] = np.inf
+        with np.errstate(all='ignore'):
+            ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, num_threads=0)
+        for wpo in (0, 1, 4):
+            out = pnp_uncert_device(*[_dv(a, dev) for a in (x2d, istd, x3d, K, ur, vr)], 0.5, 0.6, _dv(thr, dev), True, flags=(wpo << 8))
+            torch.cuda.synchronize()
+            valid, pose = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy()
+            assert np.isfinite(pose[valid]).all(), (trial, mode, wpo)
+            assert np.array_equal(valid, ref[0]), (trial, mode, wpo)
