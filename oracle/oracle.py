@@ -12,8 +12,9 @@ Reference rows restated here in numpy, paths relative to /root/
   R10 dim / NOC decode ........ monorun/core/bbox_3d/dim_coder/multiclass_norm_dim_coder.py:28-36,
                                 monorun/core/bbox_3d/coord_coder/noc_coder.py:50-73
   R11 log-std decode .......... monorun/core/bbox_3d/proj_error_coder/distance_invar_proj_error_coder.py:39-60
-  R12 roi_align(coord_2d) ..... monorun/models/roi_heads/monorun_roi_head.py:521-523 (analytic interior form;
-                                mmcv absent -> border behaviour unpinned)
+  R12 roi_align(coord_2d) ..... monorun/models/roi_heads/monorun_roi_head.py:521-523 (`roi_grid`: analytic interior form;
+                                `roi_align_avg`: the published mmcv algorithm restated — mmcv absent -> parity UNPINNED,
+                                checked against closed forms in tests/test_roi_align.py)
   R13 cov_correction .......... distance_invar_proj_error_coder.py:62-63
 """
 import ctypes
