@@ -124,18 +124,46 @@ def main():
     batch = syn.make_batch(B=B_PER_GPU, hw=HW, seed=SEED + rank)
     np_inputs = syn.pnp_boundary(batch, planar=True)     # the strided views the reference's head hands to the PnP
     x2d, istd, x3d, K, ur, vr, thr = [to_dev(a, dev) for a in np_inputs]
-    packed = PackedResults(B_PER_GPU, dev)
-    launch = PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr,
-                       inlier_opt_only=True, flags=(args.waves << 8), out=packed)
-    gathered = torch.empty(world * packed.buf.numel(), dtype=torch.uint8, device=dev) if use_dist else None
+    # two result buffers: with N > 1 the all-gather of step i overlaps the kernel of step i+1
+    packs = [PackedResults(B_PER_GPU, dev) for _ in range(2)]
+    launches = [PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr,
+                          inlier_opt_only=True, flags=(args.waves << 8), out=pk) for pk in packs]
+    packed, launch = packs[0], launches[0]
+    gathered = [torch.empty(world * pk.buf.numel(), dtype=torch.uint8, device=dev) for pk in packs] if use_dist else None
+    # exchange: a private RCCL communicator driven directly (ncclAllGather on a side stream, ~5 us of host time per call);
+    # MR_BENCH_COMM=torch, or any failure to set it up, falls back to torch.distributed's (synchronous) all-gather
+    rccl = None
+    if use_dist and os.environ.get('MR_BENCH_COMM', 'rccl') == 'rccl':
+        try:
+            from monorun_amd.parallel import RcclAllGather
+            rccl = RcclAllGather(dev)
+        except Exception as e:                                   # noqa: BLE001 — any setup problem: use the c10d path
+            print(f'[bench] direct RCCL path unavailable ({e}); using torch.distributed', file=sys.stderr)
+            rccl = None
+    done = [None, None]
+    counter = [0]
 
     def step():
-        launch.run()
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, packed.buf)
+        if not use_dist:
+            launch.run()
+            return
+        k = counter[0] & 1
+        counter[0] += 1
+        if rccl is None:
+            launches[k].run()
+            dist.all_gather_into_tensor(gathered[k], packs[k].buf)
+            return
+        if done[k] is not None:
+            torch.cuda.current_stream().wait_event(done[k])     # the gather that read buffer k finished before it is rewritten
+        launches[k].run()
+        done[k] = rccl.gather(packs[k].buf, gathered[k])
 
     def fence():
         if use_dist:
+            for k in range(2):
+                if done[k] is not None:
+                    torch.cuda.current_stream().wait_event(done[k])
+                    done[k] = None
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +261,7 @@ def main():
                                    'istd, fp32 storage, channel-planar (NCHW-view) layout, per GPU',
                        'objects_per_gpu': B_PER_GPU, 'points_per_object': P, 'seed': SEED,
                        'stages': 'istd mask + K0 consensus initialiser (32 hyp.) + LM (Ceres-1.14 semantics, fp64) + covariance',
-                       'parallelism': f'objects sharded x{world}' + (', 1 RCCL all-gather of 88 B/object per step' if world > 1 else '')},
+                       'parallelism': f'objects sharded x{world}' + (', 1 RCCL all-gather of 88 B/object per step' + (' on a side stream, overlapped with the next step' if rccl is not None else '') if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
                          'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)),
@@ -250,6 +278,8 @@ def main():
             line['speedup_vs_cpu_1thread'] = line['value'] / one['value']
             line['speedup_vs_cpu_all_cores'] = line['value'] / allc['value']
         print(json.dumps(line))
+    if rccl is not None:
+        rccl.close()
     if use_dist:
         dist.destroy_process_group()
 
