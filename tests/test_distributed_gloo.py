@@ -88,3 +88,31 @@ def test_shard_bounds_cover_everything_once():
     p.pose[:] = 1.5; p.cov[:] = 2.5; p.tr[:] = 3.5; p.valid[:] = 1
     u = PackedResults.unpack(p.buf.view(1, -1), 5)
     assert (u['pose'] == 1.5).all() and (u['cov'] == 2.5).all() and (u['tr'] == 3.5).all() and u['valid'].all()
+
+
+@pytest.mark.gpu
+def test_direct_rccl_all_gather_world_size_1():
+    """parallel.RcclAllGather (private RCCL communicator, ncclAllGather on a side stream) inside a 1-rank nccl job — the only
+    world size a 1-GPU box offers: bootstrap through torch.distributed, stream ordering, byte-exact result."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, ROOT_DIR)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29571')
+        torch.cuda.set_device(0); dev = torch.device('cuda', 0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        from monorun_amd.parallel import RcclAllGather, PackedResults
+        ag = RcclAllGather(dev)
+        pk = PackedResults(100, dev)
+        out = torch.zeros(pk.buf.numel(), dtype=torch.uint8, device=dev)
+        for it in range(3):
+            pk.pose.copy_(torch.arange(400, device=dev, dtype=torch.float32).view(100, 4) + it)     # produced on the current stream
+            pk.valid.fill_(it % 2)
+            done = ag.gather(pk.buf, out)
+            torch.cuda.current_stream().wait_event(done)
+            got = PackedResults.unpack(out.view(1, -1), 100)
+            assert torch.equal(got['pose'], pk.pose) and torch.equal(got['valid'], pk.valid.bool()), it
+        ag.close(); dist.destroy_process_group(); print('RCCL_OK')
+    ''').replace('ROOT_DIR', repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert 'RCCL_OK' in r.stdout, r.stderr[-2000:]
