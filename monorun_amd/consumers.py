@@ -19,23 +19,17 @@ def score_head_inputs(yaw, t_vec, pose_cov, dimensions):
 
 
 def get_bbox_3d_result(dimensions, yaw, t_vec, scores, labels, num_classes, to_np=False):
-    bboxes_3d = torch.cat((dimensions, t_vec, yaw, scores.unsqueeze(1)), dim=1)
+    """Per-class list of (n_c, 8) rows [l, h, w, x, y, z, ry, score] (monorun_roi_head.py:606-617)."""
+    rows = torch.cat((dimensions, t_vec, yaw, scores.unsqueeze(1)), dim=1)
     if to_np:
-        bboxes_3d = bboxes_3d.cpu().numpy()
-        labels = labels.cpu().numpy()
-    return [bboxes_3d[labels == i] for i in range(num_classes)]
+        rows, labels = rows.cpu().numpy(), labels.cpu().numpy()
+    return [rows[labels == c] for c in range(num_classes)]
 
 
 def xywhr2xyxyr(boxes_xywhr):
-    boxes = torch.zeros_like(boxes_xywhr)
-    half_w = boxes_xywhr[:, 2] / 2
-    half_h = boxes_xywhr[:, 3] / 2
-    boxes[:, 0] = boxes_xywhr[:, 0] - half_w
-    boxes[:, 1] = boxes_xywhr[:, 1] - half_h
-    boxes[:, 2] = boxes_xywhr[:, 0] + half_w
-    boxes[:, 3] = boxes_xywhr[:, 1] + half_h
-    boxes[:, 4] = boxes_xywhr[:, 4]
-    return boxes
+    """[cx, cy, w, h, r] -> [x1, y1, x2, y2, r] (monorun_roi_head.py:657-677)."""
+    centre, half = boxes_xywhr[:, 0:2], boxes_xywhr[:, 2:4] / 2
+    return torch.cat((centre - half, centre + half, boxes_xywhr[:, 4:5]), dim=1)
 
 
 def nms_bev(boxes_xyxyr_list, scores_list, thr):
@@ -62,16 +56,9 @@ def nms_bev(boxes_xyxyr_list, scores_list, thr):
 
 
 def multiclass_3d_result_nms(bbox_3d_result, nms_thr=0.25, to_np=True):
-    """
-    Args:
-        bbox_3d_result (list[Tensor]): tensor shape (N, 8), in format [l, h, w, x, y, z, ry, score]
-        nms_thr (float):
-        to_np (bool):
-
-    Returns:
-        bbox_3d_result_out (list[Tensor | ndarray]), keep_inds_3d (list[Tensor | ndarray])
-    (contract of monorun_roi_head.py:619-655, including the n <= 1 branch that returns zeros(n) indices)
-    """
+    """Rotated-BEV NMS per class over a list of (n, 8) [l, h, w, x, y, z, ry, score] tensors; returns (kept rows per class,
+    kept indices per class), as numpy when to_np — the contract of monorun_roi_head.py:619-655, including its n <= 1 branch
+    that returns zeros(n) as indices."""
     big = [i for i, b in enumerate(bbox_3d_result) if b.size(0) > 1]
     kept = {}
     if big:

@@ -113,33 +113,16 @@ class PnPLaunch:
             _lib.check(code)
 
 
-def pnp_uncert(coords_2d, coords_2d_istd, coords_3d,
-               cam_mats, u_range, v_range, z_min=0.5,
-               epnp_istd_thres=1.0, epnp_ransac_thres=None,
-               inlier_opt_only=False, forward_exact_hessian=False,
-               use_6dof=False):
-    """
-    Args:
-        coords_2d (torch.Tensor): shape (Nbatch, Npoint, 2)
-        coords_2d_istd (torch.Tensor): shape (Nbatch, Npoint, 2)
-        coords_3d (torch.Tensor): shape (Nbatch, Npoint, 3)
-        cam_mats (torch.Tensor): shape (Nbatch, 3, 3) or (1, 3, 3)
-        u_range (torch.Tensor): shape (Nbatch, 2) or (1, 2)
-        v_range (torch.Tensor): shape (Nbatch, 2) or (1, 2)
-        z_min (float):
-        epnp_istd_thres (float):
-        epnp_ransac_thres (None | torch.Tensor): shape (Nbatch, )
-        inlier_opt_only (bool):
-        forward_exact_hessian (bool): only False is supported (every shipped config, e.g.
-            configs/kitti_car.py:123; the reference's exact_hessian no longer runs on torch>=2)
-        use_6dof (bool): accepted and ignored, exactly as in the reference (pnp_uncert.py:11)
+def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
+               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False):
+    """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
 
-    Returns:
-        ret_val (Tensor): shape (Nbatch, ), validity bool mask
-        r_vec (Tensor): shape (Nbatch, 1)
-        t_vec (Tensor): shape (Nbatch, 3)
-        pose_cov (Tensor): shape (Nbatch, 4, 4), covariance matrices of [yaw, t_vec]
-        inlier_mask (Tensor): shape (Nbatch, Npoint), inlier bool mask
+    coords_2d / coords_2d_istd (B,P,2), coords_3d (B,P,3), cam_mats (B|1,3,3), u_range / v_range (B|1,2),
+    epnp_ransac_thres (B,) or None — any device; host tensors are staged through the GPU.
+    forward_exact_hessian: only False (every shipped config, e.g. configs/kitti_car.py:123; the reference's exact Hessian no
+    longer runs on torch >= 2).  use_6dof: accepted and ignored, exactly as in the reference (pnp_uncert.py:11).
+    Returns (ret_val (B,) bool, r_vec (B,1) yaw, t_vec (B,3), pose_cov (B,4,4) covariance of [yaw, t], inlier_mask (B,P) bool)
+    on the device and in the dtype of coords_2d.
     """
     if forward_exact_hessian:
         raise NotImplementedError('forward_exact_hessian=True is not supported (unused by every reference config)')
@@ -166,46 +149,22 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d,
 @PNP.register_module()
 class PnPUncert(torch.nn.Module):
 
-    def __init__(self, z_min=0.5,
-                 epnp_istd_thres=0.6,
-                 inlier_opt_only=True,
-                 coord_istd_normalize=False,
-                 forward_exact_hessian=False,
-                 use_6dof=False,
-                 eps=1e-6):
-        """Uncertainty-2D PnP (same constructor as the reference, pnp_uncert.py:93-99).
+    def __init__(self, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, coord_istd_normalize=False,
+                 forward_exact_hessian=False, use_6dof=False, eps=1e-6):
+        """Module form (constructor keywords of the reference, pnp_uncert.py:93-99; no parameters, no buffers).
+        epnp_istd_thres: a point is an istd inlier when both of its istd components reach this factor times the object's
+        mean; inlier_opt_only: the LM refines on the inlier set only; coord_istd_normalize: divide the istd map by its
+        per-object mean (clamped at eps) first."""
+        super().__init__()
+        self.z_min, self.epnp_istd_thres, self.inlier_opt_only = z_min, epnp_istd_thres, inlier_opt_only
+        self.coord_istd_normalize, self.eps = coord_istd_normalize, eps
+        self.forward_exact_hessian, self.use_6dof = forward_exact_hessian, use_6dof
 
-        Args:
-            z_min (float):
-            epnp_istd_thres (float): points with istd greater than (thres
-                * istd_mean) will be kept as inliers
-            inlier_opt_only (bool): whether to use inliers or all points for
-                non-linear optimization
-        """
-        super(PnPUncert, self).__init__()
-        self.z_min = z_min
-        self.epnp_istd_thres = epnp_istd_thres
-        self.inlier_opt_only = inlier_opt_only
-        self.coord_istd_normalize = coord_istd_normalize
-        self.forward_exact_hessian = forward_exact_hessian
-        self.use_6dof = use_6dof
-        self.eps = eps
-
-    def forward(self,
-                coords_2d, coords_2d_istd,
-                coords_3d,
-                cam_mats,
-                u_range, v_range, epnp_ransac_thres=None):
+    def forward(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, epnp_ransac_thres=None):
+        istd = coords_2d_istd
         if self.coord_istd_normalize:
-            mean = torch.mean(coords_2d_istd, dim=(1, 2), keepdim=True)
-            coords_2d_istd = coords_2d_istd / mean.clamp(min=self.eps)
-        return pnp_uncert(
-            coords_2d, coords_2d_istd,
-            coords_3d,
-            cam_mats,
-            u_range, v_range, z_min=self.z_min,
-            epnp_istd_thres=self.epnp_istd_thres,
-            epnp_ransac_thres=epnp_ransac_thres,
-            inlier_opt_only=self.inlier_opt_only,
-            forward_exact_hessian=self.forward_exact_hessian,
-            use_6dof=self.use_6dof)
+            istd = istd / istd.mean(dim=(1, 2), keepdim=True).clamp(min=self.eps)
+        return pnp_uncert(coords_2d, istd, coords_3d, cam_mats, u_range, v_range, z_min=self.z_min,
+                          epnp_istd_thres=self.epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres,
+                          inlier_opt_only=self.inlier_opt_only, forward_exact_hessian=self.forward_exact_hessian,
+                          use_6dof=self.use_6dof)

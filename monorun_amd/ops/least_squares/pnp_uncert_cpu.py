@@ -24,36 +24,19 @@ def _to_dev(a, dev):
     return d
 
 
-def u2d_pnp_cpu(coords_2d, coords_2d_istd,
-                coords_3d,
-                cam_mats,
-                u_range, v_range, z_min=0.5,
-                epnp_istd_thres=1.0,
-                epnp_ransac_thres=None,
-                inlier_opt_only=False,
-                with_pose_cov=True):
-    """
-    Args:
-        coords_2d (ndarray): shape (Nbatch, Npoint, 2)
-        coords_2d_istd (ndarray): shape (Nbatch, Npoint, 2)
-        coords_3d (ndarray): shape (Nbatch, Npoint, 3)
-        cam_mats (ndarray): shape (Nbatch, 3, 3) or (1, 3, 3)
-        u_range (ndarray): shape (Nbatch, 2) or (1, 2)
-        v_range (ndarray): shape (Nbatch, 2) or (1, 2)
-        z_min (float):
-        epnp_istd_thres (float):
-        epnp_ransac_thres (None | ndarray): shape (Nbatch, )
-        inlier_opt_only (bool):
+def u2d_pnp_cpu(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
+                epnp_ransac_thres=None, inlier_opt_only=False, with_pose_cov=True):
+    """Batched pose solve on numpy arrays (keyword names and defaults are the reference's, pnp_uncert_cpu.py:128-135).
 
-    Returns:
-        ret_val (ndarray): shape (Nbatch, ), validity bool mask
-        yaw (ndarray): shape (Nbatch, 1)
-        t_vec (ndarray): shape (Nbatch, 3)
-        pose_cov (ndarray): shape (Nbatch, 4, 4), covariance matrices
-            of [yaw, t_vec]; here (J^T J)^-1 with the solver's Jacobian, as Ceres'
-            Covariance returns it (pnp_uncert_cpu.cpp:279-291); None if not with_pose_cov
-        tr_radius (ndarray): shape (Nbatch, 1), trust region radius
-        inlier_mask (ndarray): shape (Nbatch, Npoint), inlier bool mask
+    Inputs, B objects with P correspondences each:
+      coords_2d (B,P,2) image points, coords_2d_istd (B,P,2) their inverse standard deviations, coords_3d (B,P,3)
+      object-frame points; cam_mats (B|1,3,3); u_range / v_range (B|1,2) clip intervals of the projection; z_min depth
+      clamp; epnp_istd_thres the istd-inlier factor; epnp_ransac_thres (B,) consensus thresholds in pixels or None;
+      inlier_opt_only: refine on the inlier set only; with_pose_cov: also return the covariance.
+    Output 6-tuple (float32 / bool numpy arrays):
+      ret_val (B,) success flags, yaw (B,1), t_vec (B,3), pose_cov (B,4,4) = (J^T J)^-1 of [yaw, t] with the solver's
+      Jacobian, as Ceres' Covariance reports it (pnp_uncert_cpu.cpp:279-291), or None; tr_radius (B,1) final trust-region
+      radius; inlier_mask (B,P).
     """
     bn = coords_2d.shape[0]
     pn = coords_2d.shape[1]
