@@ -33,6 +33,7 @@ extern "C" {
 #define MR_F32 0
 #define MR_F16 1
 #define MR_F64 2
+#define MR_BF16 3                      /* head outputs only (mr_noc_decode_batched, mr_pnp_from_head_batched) */
 
 /* error codes */
 #define MR_OK                 0
@@ -110,7 +111,8 @@ void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *
 
 /*
  * Fused NOC-head post-processing ("K2"): from the raw head output to the PnP-boundary tensors.
- *   all_pred  (B, 2*C*5, h, w) f32  — conv_final output (C = num_classes, or 1 if class_agnostic)
+ *   all_pred  (B, 2*C*5, h, w) f32 / f16 / bf16 (pred_dtype; converted exactly to f32, all arithmetic is f32) — conv_final
+ *             output (C = num_classes, or 1 if class_agnostic)
  *   labels (B) int64, flip (B) u8, dim (B,3) f32 normalised dims, dim_var (B,3) f32 or NULL,
  *   rois (B,4) f32 xyxy in the test-scale image
  * writes channel-planar maps
@@ -122,7 +124,7 @@ void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *
  *   Resize3D / RandomFlip3D / Pad3D) the RoIAlign taps are sampled exactly, mmcv border rules included.
  */
 int mr_noc_decode_batched(
-    const float *all_pred, const int64_t *labels, const uint8_t *flip,
+    const void *all_pred, int pred_dtype /* MR_F32 | MR_F16 | MR_BF16 */, const int64_t *labels, const uint8_t *flip,
     const float *dim, const float *dim_var, const float *rois,
     int B, int num_classes, int class_agnostic, int h, int w,
     const float *dim_means /* (C,3) */, const float *dim_stds /* (C,3) */,
@@ -145,7 +147,7 @@ int mr_noc_decode_batched(
  * distance_invar_proj_error_coder.py:62-63, monorun_roi_head.py:530-534) — written by the same launch.
  */
 int mr_pnp_from_head_batched(
-    const float *all_pred, const int64_t *labels, const uint8_t *flip,
+    const void *all_pred, int pred_dtype, const int64_t *labels, const uint8_t *flip,
     const float *dim, const float *dim_var, const float *rois,
     int B, int num_classes, int class_agnostic, int h, int w,
     const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,

@@ -15,7 +15,7 @@ SRC = os.path.join(_HERE, 'csrc', 'monorun_pnp.hip')
 INCLUDE = os.path.join(_ROOT, 'include')
 SO = os.environ.get('MR_PNP_SO') or os.path.join(_HERE, 'libmonorun_pnp.so')     # MR_PNP_SO: A/B-test another build of the library
 
-MR_F32, MR_F16, MR_F64 = 0, 1, 2
+MR_F32, MR_F16, MR_F64, MR_BF16 = 0, 1, 2, 3
 MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
 MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES = 0x4, 0x8, 0x10
 MR_WAVES_SHIFT = 8
@@ -76,12 +76,12 @@ def load():
     if hasattr(lib, 'mr_noc_decode_batched'):
         lib.mr_noc_decode_batched.restype = i32
         lib.mr_noc_decode_batched.argtypes = [
-            vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+            vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
             vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
             vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.mr_pnp_from_head_batched.restype = i32
     lib.mr_pnp_from_head_batched.argtypes = [
-        vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+        vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
         vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, f32, f32,
         vp, i32, vp, vp, i32, f32, f32, i32, i32,
         vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, vp, vp]

@@ -36,7 +36,8 @@ constexpr int kRedN = 32;           // doubles per wave in the cross-wave reduct
 // The per-object / per-pixel arithmetic is shared with the fused path of the PnP kernel (decoded maps
 // written straight into its LDS tile, never to HBM).
 struct DecodeArgs {
-    const float *all_pred; const long long *labels; const uint8_t *flip; const float *dim, *dim_var, *rois;
+    const void *all_pred; int pred_dtype;      // head output: MR_F32, MR_F16 or MR_BF16 (autocast pipelines); decoded in fp32
+    const long long *labels; const uint8_t *flip; const float *dim, *dim_var, *rois;
     int B, C, agnostic, h, w;
     const float *dim_means, *dim_stds; float noc_mean[3], noc_std[3];
     float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
@@ -96,7 +97,13 @@ __global__ void __launch_bounds__(256) roi_align_avg_kernel(const float *in, con
                                  r[4] * spatial_scale, ph, pw, out_h, out_w, sampling_ratio, aligned);
 }
 
-struct DecodeObj { float dm[3], dv[3]; float x1, y1, x2, y2, su, sv, thr; const float *base; int ch_noc, ch_ls; };
+struct DecodeObj { float dm[3], dv[3]; float x1, y1, x2, y2, su, sv, thr; long long base; int ch_noc, ch_ls; };   // base: element offset of the object
+
+__device__ __forceinline__ float pred_at(const DecodeArgs &a, long long i) {
+    if (a.pred_dtype == MR_F32) return ((const float *)a.all_pred)[i];
+    if (a.pred_dtype == MR_F16) return __half2float(((const __half *)a.all_pred)[i]);
+    return __uint_as_float((unsigned)((const unsigned short *)a.all_pred)[i] << 16);            // bfloat16
+}
 
 __device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, DecodeObj &o) {
 #pragma clang fp contract(off)
@@ -124,7 +131,7 @@ __device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, Decode
         v_last = (y1 - 0.5f) + ((float)(a.h - 1) + 0.5f) * o.sv; v_first = (y1 - 0.5f) + 0.5f * o.sv;
     }
     o.thr = a.ratio * (v_last - v_first);
-    o.base = a.all_pred + (long long)b * (2 * Cn * 5) * hw;
+    o.base = (long long)b * (2 * Cn * 5) * hw;
     o.ch_noc = f * 5 * Cn + 3 * c; o.ch_ls = f * 5 * Cn + 3 * Cn + 2 * c;
 }
 
@@ -135,7 +142,7 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
     float xv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float noc = o.base[(long long)(o.ch_noc + k) * hw + p];
+        const float noc = pred_at(a, o.base + (long long)(o.ch_noc + k) * hw + p);
         const float part = noc * a.noc_std[k] + a.noc_mean[k];
         c3d[k] = part * o.dm[k];
         xv[k] = o.dv[k] * (part * part);
@@ -143,7 +150,7 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
     const float v2[2] = { 0.5f * (xv[0] + xv[2]), xv[1] };
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const float ls = o.base[(long long)(o.ch_ls + k) * hw + p];
+        const float ls = pred_at(a, o.base + (long long)(o.ch_ls + k) * hw + p);
         float lspx;
         if (a.has_var) lspx = 0.5f * logf((v2[k] * a.k_epi + expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
         else lspx = ls + 0.0f;                                    // log(sd / sd)
@@ -519,7 +526,7 @@ int mr_pnp_uncert_batched(
     }
 }
 
-static int fill_decode_args(DecodeArgs &a, const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim,
+static int fill_decode_args(DecodeArgs &a, const void *all_pred, int pred_dtype, const int64_t *labels, const uint8_t *flip, const float *dim,
                             const float *dim_var, const float *rois, int B, int num_classes, int class_agnostic, int h, int w,
                             const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
                             double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale,
@@ -527,7 +534,8 @@ static int fill_decode_args(DecodeArgs &a, const float *all_pred, const int64_t 
     if (B < 0 || h < 1 || w < 1 || num_classes < 1) return MR_ERR_BAD_ARGUMENT;
     if (!all_pred || !labels || !flip || !dim || !rois || !dim_means || !dim_stds || !noc_means || !noc_stds) return MR_ERR_BAD_ARGUMENT;
     memset(&a, 0, sizeof a);
-    a.all_pred = all_pred; a.labels = (const long long *)labels; a.flip = flip; a.dim = dim; a.dim_var = dim_var; a.rois = rois;
+    if (pred_dtype != MR_F32 && pred_dtype != MR_F16 && pred_dtype != MR_BF16) return MR_ERR_UNSUPPORTED;
+    a.all_pred = all_pred; a.pred_dtype = pred_dtype; a.labels = (const long long *)labels; a.flip = flip; a.dim = dim; a.dim_var = dim_var; a.rois = rois;
     a.B = B; a.C = num_classes; a.agnostic = class_agnostic; a.h = h; a.w = w;
     a.dim_means = dim_means; a.dim_stds = dim_stds;
     for (int k = 0; k < 3; ++k) { a.noc_mean[k] = noc_means[k]; a.noc_std[k] = noc_stds[k]; }
@@ -542,7 +550,7 @@ static int fill_decode_args(DecodeArgs &a, const float *all_pred, const int64_t 
 }
 
 int mr_noc_decode_batched(
-    const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
+    const void *all_pred, int pred_dtype, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
     int B, int num_classes, int class_agnostic, int h, int w,
     const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
     double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
@@ -552,7 +560,7 @@ int mr_noc_decode_batched(
     if (coord_2d_map && (map_h < 1 || map_w < 1)) return MR_ERR_BAD_ARGUMENT;
     if (B > 65535) return MR_ERR_BAD_ARGUMENT;
     DecodeArgs a;
-    const int rc = fill_decode_args(a, all_pred, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
+    const int rc = fill_decode_args(a, all_pred, pred_dtype, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
                                     noc_means, noc_stds, proj_scaling_denominator, ref_focal_y, epistemic_std_gain, std_scale, ransac_thres_ratio);
     if (rc != MR_OK) return rc;
     if (!coords_2d || !coords_2d_istd || !coords_3d) return MR_ERR_BAD_ARGUMENT;
@@ -566,7 +574,7 @@ int mr_noc_decode_batched(
 }
 
 int mr_pnp_from_head_batched(
-    const float *all_pred, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
+    const void *all_pred, int pred_dtype, const int64_t *labels, const uint8_t *flip, const float *dim, const float *dim_var, const float *rois,
     int B, int num_classes, int class_agnostic, int h, int w,
     const float *dim_means, const float *dim_stds, const float *noc_means, const float *noc_stds,
     double proj_scaling_denominator, double ref_focal_y, double epistemic_std_gain, float std_scale, float ransac_thres_ratio,
@@ -583,7 +591,7 @@ int mr_pnp_from_head_batched(
     if ((cam_batch != 1 && cam_batch != B) || (range_batch != 1 && range_batch != B)) return MR_ERR_BAD_ARGUMENT;
     PnpArgs a;
     memset(&a, 0, sizeof a);
-    const int rc = fill_decode_args(a.dec, all_pred, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
+    const int rc = fill_decode_args(a.dec, all_pred, pred_dtype, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
                                     noc_means, noc_stds, proj_scaling_denominator, ref_focal_y, epistemic_std_gain, std_scale, ransac_thres_ratio);
     if (rc != MR_OK) return rc;
     a.dec.dims = dims; a.dec.dims_var = dims_var;

@@ -72,6 +72,17 @@ def _clip_ranges(img_shapes, allowed_border, dev):
     return hit
 
 
+_PRED_DTYPES = {torch.float32: _lib.MR_F32, torch.float16: _lib.MR_F16, torch.bfloat16: _lib.MR_BF16}
+
+
+def _head_output(all_pred, dev):
+    """The NOC head's output as the kernels take it: fp32, fp16 or bf16 (autocast) is read as is, anything else -> fp32."""
+    x = all_pred.detach()
+    if x.dtype not in _PRED_DTYPES or x.device != dev:
+        x = x.to(device=dev, dtype=x.dtype if x.dtype in _PRED_DTYPES else torch.float32)
+    return (x if x.is_contiguous() else x.contiguous()), _PRED_DTYPES[x.dtype]
+
+
 def _coord_map_args(coord_2d, dev):
     """(pointer, H, W) of the optional coord_2d map for the C ABI.  A converted copy may be released as soon as this
     returns: the caching allocator is stream-ordered and the launch that reads it is the next thing enqueued."""
@@ -124,7 +135,7 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
     Cn = 1 if class_agnostic else num_classes
     assert ch == 2 * Cn * 5, f'all_pred has {ch} channels, expected {2 * Cn * 5}'
     f32 = dict(device=dev, dtype=torch.float32)
-    ap = all_pred.detach().to(**f32).contiguous()
+    ap, ap_dt = _head_output(all_pred, dev)
     lab = labels.detach().to(device=dev, dtype=torch.int64).contiguous()
     if isinstance(flip, bool):
         fl = torch.full((B,), int(flip), device=dev, dtype=torch.uint8)
@@ -145,7 +156,7 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
     if B > 0:
         with torch.cuda.device(dev):
             _lib.check(lib.mr_noc_decode_batched(
-                ap.data_ptr(), lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
+                ap.data_ptr(), ap_dt, lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
                 B, num_classes, int(class_agnostic), h, w, mu.data_ptr(), sd.data_ptr(), nm.data_ptr(), ns.data_ptr(),
                 float(ref_length * ref_focal_y * target_std), float(ref_focal_y), float(epistemic_std_gain), float(std_scale),
                 float(epnp_ransac_thres_ratio) if epnp_ransac_thres_ratio is not None else -1.0,
@@ -178,7 +189,7 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
         if x.dtype != dt or x.device != dev:
             x = x.to(device=dev, dtype=dt)
         return x if x.is_contiguous() else x.contiguous()
-    ap, lab, dm = prep(all_pred), prep(labels, torch.int64), prep(dim)
+    (ap, ap_dt), lab, dm = _head_output(all_pred, dev), prep(labels, torch.int64), prep(dim)
     fl = _flip_flags(flip, B, dev)
     dv = prep(dim_var) if dim_var is not None else None
     r = prep(rois)
@@ -209,7 +220,7 @@ def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img
         mp, mh, mw = _coord_map_args(coord_2d, dev)
         with torch.cuda.device(dev):
             _lib.check(lib.mr_pnp_from_head_batched(
-                ap.data_ptr(), lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
+                ap.data_ptr(), ap_dt, lab.data_ptr(), fl.data_ptr(), dm.data_ptr(), dv.data_ptr() if dv is not None else None, r.data_ptr(),
                 B, num_classes, int(class_agnostic), h, w, mu.data_ptr(), sd.data_ptr(), nm.data_ptr(), ns.data_ptr(),
                 float(ref_length * ref_focal_y * target_std), float(ref_focal_y), float(epistemic_std_gain), float(std_scale),
                 float(epnp_ransac_thres_ratio) if epnp_ransac_thres_ratio is not None else -1.0,

@@ -187,3 +187,27 @@ def test_fused_calibration_and_distance_correction(dev, g3):
         assert a['ret_val'].dtype == torch.bool and a['pose_cov_calib'].shape == (B, 4, 4)
         ok = a['ret_val']
         torch.testing.assert_close(a['pose_cov_calib'][ok], b['pose_cov_calib'][ok], rtol=2e-6, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_half_precision_head_outputs(dev, g3, dtype):
+    """fp16 / bf16 head outputs (autocast pipelines) are read as they are and widened exactly: results are bit-identical to
+    feeding the same values as fp32, in K2 and in the fused kernel."""
+    from monorun_amd.pose_head import noc_decode, pnp_from_head
+    rng = np.random.default_rng(12)
+    B = g3['all_pred'].shape[0]
+    rois = np.stack([rng.uniform(100, 900, B), rng.uniform(50, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(30, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    ap_lo = t(g3['all_pred']).to(dtype)
+    ap_32 = ap_lo.to(torch.float32)
+    args = (t(g3['labels']), t(g3['flip']), t(g3['dim']), t(g3['dim_var']), t(rois))
+    a, b_ = noc_decode(ap_lo, *args), noc_decode(ap_32, *args)
+    for k in ('coords_2d', 'coords_2d_istd', 'coords_3d', 'dims', 'dims_var', 'ransac_thr'):
+        assert torch.equal(a[k], b_[k]), k
+    K = t(syn.KITTI_K[None].astype(np.float32))
+    img = np.array([[375.0, 1242.0]], np.float32)
+    o1, o2 = pnp_from_head(ap_lo, *args, K, img), pnp_from_head(ap_32, *args, K, img)
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
