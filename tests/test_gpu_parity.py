@@ -61,7 +61,7 @@ def _cmp(gpu, ref, tag=''):
 
 
 @pytest.mark.parametrize('planar', [True, False])
-@pytest.mark.parametrize('wpo', [0, 1, 2, 4, 8])
+@pytest.mark.parametrize('wpo', [0, 1, 2, 3, 4, 8])
 def test_config2_batch_matches_oracle(dev, orc, planar, wpo):
     """Seeded config-2 objects: mask/K0 bit-exact, pose 1e-4, cov 1e-5 — both layouts the pipeline
     produces (numpy pairwise vs sequential istd mean) and every wavefronts-per-object variant."""
