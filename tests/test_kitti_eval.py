@@ -193,6 +193,9 @@ def test_gpu_eval_edge_cases():
     # single class given as a bare string, coco-style summary
     t1, d1 = ev.kitti_eval(gts, dts, 'Car', eval_types=['bbox', 'bev', '3d'], criteria='R40')
     assert 'Overall' not in t1 and 'KITTI/Car_3D_moderate_strict' in d1
+    t2, d2 = ev.kitti_eval(gts, dts, CLASSES, eval_types=['bbox'], criteria='R11')            # 2-D only: no bev / 3d lines or keys
+    assert 'bev ' not in t2 and '3d  ' not in t2 and 'aos' in t2 and not any('_3D_' in k or '_BEV_' in k for k in d2)
+    assert abs(d2['KITTI/Car_2D_moderate_strict'] - ke.get_map(ke.eval_class(gts, dts, [0, 1, 2], [0, 1, 2], 0, ke.KITTI_MIN_OVERLAPS[:, :, [0, 1, 2]])['precision'], 'R11')[0, 1, 0]) < 1e-9
     coco = ev.kitti_eval_coco_style(gts, dts, CLASSES, criteria='R40')
     assert coco.count('coco AP@') == 3 and 'Car coco AP@0.50:0.05:0.95:' in coco
     mo10 = np.zeros((10, 3, 1)); mo10[:, :, 0] = np.linspace(0.5, 0.95, 10)[:, None]
