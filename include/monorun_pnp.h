@@ -17,6 +17,15 @@
  * that the caller must free; device entry points are asynchronous on the given HIP stream and touch
  * only caller-owned memory.  Numerical failure of a solve is reported per object in `valid`,
  * never as an error code (pnp_uncert_cpu.py:119-125).
+ *
+ * POINTER CONVENTION.  In every `mr_*` entry point EVERY data pointer — tensors, per-object vectors, the small
+ * constant tables (cam_mats, u_range, v_range, dim_means, dim_stds, noc_means, noc_stds, cov_calib_logscale, offsets,
+ * thresholds ...) and all outputs — is a DEVICE pointer (hipMalloc / torch CUDA tensor memory), dereferenced only by
+ * the kernels, in stream order.  The only host pointers are the three `*_strides` arrays of mr_pnp_uncert_batched
+ * (3 x int64, read before the call returns) and `stream`.  The three reference entry points `pnp_uncert`,
+ * `pnp_noc_uncert`, `pnp_noc_cov_uncert` keep the reference's convention instead: HOST fp64 buffers, blocking.
+ * Multi-device: a call runs on the CURRENT HIP device (hipSetDevice / torch.cuda.device); per-device state inside the
+ * library (LDS opt-in, staging buffers of the host entry points) is keyed by device.
  */
 #ifndef MONORUN_PNP_H_
 #define MONORUN_PNP_H_

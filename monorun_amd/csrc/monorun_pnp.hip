@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <type_traits>
@@ -17,6 +18,7 @@ constexpr int kMaxChunks = 128;     // 64-point chunks per object (P <= 8192; LD
 constexpr int kHyp = 32;            // K0 hypotheses (the reference's RANSAC runs 30 iterations)
 constexpr uint32_t kK0Seed = 0x9E3779B9u;
 constexpr int kRedN = 32;           // doubles per wave in the cross-wave reduction scratch
+constexpr int kMaxDevices = 64;     // per-device library state (LDS opt-in, host-entry staging) is keyed by HIP device id
 #ifndef MR_MIN_WAVES
 #define MR_MIN_WAVES 3              // waves per SIMD the register allocator must allow: fp16 / fp64 storage (<= 168 VGPRs)
 #endif
@@ -39,7 +41,7 @@ struct DecodeArgs {
     const void *all_pred; int pred_dtype;      // head output: MR_F32, MR_F16 or MR_BF16 (autocast pipelines); decoded in fp32
     const long long *labels; const uint8_t *flip; const float *dim, *dim_var, *rois;
     int B, C, agnostic, h, w;
-    const float *dim_means, *dim_stds; float noc_mean[3], noc_std[3];
+    const float *dim_means, *dim_stds, *noc_means, *noc_stds;     // device pointers: (C,3), (C,3), (3), (3)
     float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
     float *c2d, *istd, *c3d, *dims, *dims_var, *thr;
     const float *map2d; int map_h, map_w;      // optional coord_2d map (2, H, W): exact RoIAlign sampling instead of the analytic grid
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(256) roi_align_avg_kernel(const float *in, con
                                  r[4] * spatial_scale, ph, pw, out_h, out_w, sampling_ratio, aligned);
 }
 
-struct DecodeObj { float dm[3], dv[3]; float x1, y1, x2, y2, su, sv, thr; long long base; int ch_noc, ch_ls; };   // base: element offset of the object
+struct DecodeObj { float dm[3], dv[3], nm[3], ns[3]; float x1, y1, x2, y2, su, sv, thr; long long base; int ch_noc, ch_ls; };   // base: element offset of the object
 
 __device__ __forceinline__ float pred_at(const DecodeArgs &a, long long i) {
     if (a.pred_dtype == MR_F32) return ((const float *)a.all_pred)[i];
@@ -117,6 +119,7 @@ __device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, Decode
         const float sd = a.dim_stds[lab * 3 + k];
         o.dm[k] = a.dim[b * 3 + k] * sd + a.dim_means[lab * 3 + k];
         o.dv[k] = a.has_var ? a.dim_var[b * 3 + k] * (sd * sd) : 0.0f;
+        o.nm[k] = a.noc_means[k]; o.ns[k] = a.noc_stds[k];
     }
     const float x1 = a.rois[b * 4 + 0], y1 = a.rois[b * 4 + 1], x2 = a.rois[b * 4 + 2], y2 = a.rois[b * 4 + 3];
     o.x1 = x1; o.y1 = y1;
@@ -143,7 +146,7 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float noc = pred_at(a, o.base + (long long)(o.ch_noc + k) * hw + p);
-        const float part = noc * a.noc_std[k] + a.noc_mean[k];
+        const float part = noc * o.ns[k] + o.nm[k];
         c3d[k] = part * o.dm[k];
         xv[k] = o.dv[k] * (part * part);
     }
@@ -166,9 +169,10 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
 }
 
 __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
-    const int b = blockIdx.y;
     const int hw = a.h * a.w;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int bpo = (hw + 255) >> 8;                   // blocks per object; 1-D grid: B * bpo <= 2^31 - 1
+    const int b = blockIdx.x / bpo;
+    const int p = (blockIdx.x - b * bpo) * 256 + threadIdx.x;
     DecodeObj o;
     decode_object(a, b, o);
     if (p == 0) {
@@ -397,7 +401,7 @@ bool build_plan(PairwisePlan &pl, int P) {
     return true;
 }
 
-int g_last_hip_error = 0;
+std::atomic<int> g_last_hip_error{0};
 unsigned long long *g_stamps = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
@@ -413,11 +417,14 @@ int launch(const PnpArgs &a, hipStream_t st) {
     const size_t lds = lds_bytes(a, WPO);
     if (lds > 160 * 1024) return MR_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {
-        static std::mutex mu; static size_t granted = 0;
+        // the opt-in is a per-device function attribute: remember what was granted on each device
+        static std::mutex mu; static size_t granted[kMaxDevices] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lk(mu);
-        if (lds > granted) {
+        if (dev < 0 || dev >= kMaxDevices || lds > granted[dev]) {
             HIP_TRY(hipFuncSetAttribute((const void *)pnp_uncert_kernel<T, WPO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            granted = lds;
+            if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
         }
     }
     hipLaunchKernelGGL((pnp_uncert_kernel<T, WPO>), dim3(a.B), dim3(64 * WPO), lds, st, a);
@@ -538,7 +545,7 @@ static int fill_decode_args(DecodeArgs &a, const void *all_pred, int pred_dtype,
     a.all_pred = all_pred; a.pred_dtype = pred_dtype; a.labels = (const long long *)labels; a.flip = flip; a.dim = dim; a.dim_var = dim_var; a.rois = rois;
     a.B = B; a.C = num_classes; a.agnostic = class_agnostic; a.h = h; a.w = w;
     a.dim_means = dim_means; a.dim_stds = dim_stds;
-    for (int k = 0; k < 3; ++k) { a.noc_mean[k] = noc_means[k]; a.noc_std[k] = noc_stds[k]; }
+    a.noc_means = noc_means; a.noc_stds = noc_stds;
     // python-scalar constants of distance_invar_proj_error_coder.py:50-54, rounded the way torch rounds them
     const double e = ref_focal_y * epistemic_std_gain;
     a.k_epi = (float)(e * e);
@@ -558,7 +565,6 @@ int mr_noc_decode_batched(
     const float *coord_2d_map, int map_h, int map_w, void *stream) {
     if (B == 0) return MR_OK;
     if (coord_2d_map && (map_h < 1 || map_w < 1)) return MR_ERR_BAD_ARGUMENT;
-    if (B > 65535) return MR_ERR_BAD_ARGUMENT;
     DecodeArgs a;
     const int rc = fill_decode_args(a, all_pred, pred_dtype, labels, flip, dim, dim_var, rois, B, num_classes, class_agnostic, h, w, dim_means, dim_stds,
                                     noc_means, noc_stds, proj_scaling_denominator, ref_focal_y, epistemic_std_gain, std_scale, ransac_thres_ratio);
@@ -567,8 +573,9 @@ int mr_noc_decode_batched(
     a.c2d = coords_2d; a.istd = coords_2d_istd; a.c3d = coords_3d; a.dims = dims; a.dims_var = dims_var;
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     a.map2d = coord_2d_map; a.map_h = map_h; a.map_w = map_w;
-    const int hw = h * w;
-    hipLaunchKernelGGL(noc_decode_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    const long long blocks = (long long)((h * w + 255) / 256) * B;
+    if (blocks > 0x7fffffffLL) return MR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(noc_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return MR_OK;
 }
@@ -701,6 +708,39 @@ int mr_kitti_match(int second_pass, int metric, int compute_aos, int alpha32, in
     return MR_OK;
 }
 
+// ---- host-buffer entry points of the reference's C ABI (ext.h).  Per device: one private non-blocking stream, one pinned
+// host staging buffer and one device buffer, grown on demand and kept; a call is one async H2D copy, the kernel and one async
+// D2H copy on that stream followed by a single hipStreamSynchronize (no default-stream launch, no pageable copies, no
+// allocation in the steady state).  Calls on the same device serialise on the stage's mutex (the reference invokes these
+// serially, pnp_uncert_cpu.py:180-191); calls on different devices run concurrently.
+struct HostStage {
+    std::mutex mu;
+    hipStream_t st = nullptr;
+    void *dbuf = nullptr, *hbuf = nullptr;
+    size_t cap = 0;
+};
+static HostStage g_stage[kMaxDevices];
+
+// returns the locked stage of the current device with room for `bytes` in both buffers, or nullptr (lock not held)
+static HostStage *stage_acquire(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { g_last_hip_error = (int)hipGetLastError(); return nullptr; }
+    HostStage *s = &g_stage[dev];
+    s->mu.lock();
+    bool ok = true;
+    if (!s->st) ok = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) == hipSuccess;
+    if (ok && bytes > s->cap) {
+        const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+        if (s->dbuf) (void)hipFree(s->dbuf);
+        if (s->hbuf) (void)hipHostFree(s->hbuf);
+        s->dbuf = s->hbuf = nullptr; s->cap = 0;
+        ok = hipMalloc(&s->dbuf, want) == hipSuccess && hipHostMalloc(&s->hbuf, want, hipHostMallocDefault) == hipSuccess;
+        if (ok) s->cap = want;
+    }
+    if (!ok) { g_last_hip_error = (int)hipGetLastError(); s->mu.unlock(); return nullptr; }
+    return s;
+}
+
 // The reference's per-object entry point (ext.h:1-13).  Host fp64 buffers; one object; blocking.
 void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose,
                 int *result_val, double *result_pose, double *result_cov, double *result_tr,
@@ -710,27 +750,21 @@ void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *
     *result_tr = 0.0;
     if (pn < 1 || pn > 65535) return;
     const int P = pn < 4 ? 4 : pn;
-    // device staging: [pts2d 2P | pts3d 3P | wgt 2P | K 9 | ur 2 | vr 2 | init 4 | pose64 4 | cov64 16 | tr64 1] doubles
-    //                 + [pose 4 | cov 16 | tr 1] floats + valid
-    const size_t nd = (size_t)7 * P + 9 + 2 + 2 + 4 + 4 + 16 + 1;
-    const size_t bytes = nd * sizeof(double) + 21 * sizeof(float) + 16;
-    static std::mutex mu; static void *dbuf = nullptr; static size_t dcap = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (bytes > dcap) {
-        if (dbuf) (void)hipFree(dbuf);
-        dbuf = nullptr; dcap = 0;
-        if (hipMalloc(&dbuf, bytes) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-        dcap = bytes;
-    }
-    std::vector<double> h(nd, 0.0);
-    double *h2 = h.data(), *h3 = h2 + 2 * P, *hw = h3 + 3 * P, *hK = hw + 2 * P, *hur = hK + 9, *hvr = hur + 2, *hin = hvr + 2;
+    // staging, in doubles: [pts2d 2P | pts3d 3P | wgt 2P | K 9 | ur 2 | vr 2 | init 4 || pose64 4 | cov64 16 | tr64 1 | valid (u8, 8 bytes)]
+    //                      + [pose 4 | cov 16 | tr 1] floats (written by the kernel, not read back)
+    const size_t nin = (size_t)7 * P + 9 + 2 + 2 + 4, nout = 4 + 16 + 1 + 1;
+    const size_t bytes = (nin + nout) * sizeof(double) + 24 * sizeof(float);
+    HostStage *sg = stage_acquire(bytes);
+    if (!sg) return;
+    std::lock_guard<std::mutex> lk(sg->mu, std::adopt_lock);
+    double *h = (double *)sg->hbuf, *d = (double *)sg->dbuf;
+    double *h2 = h, *h3 = h2 + 2 * P, *hw = h3 + 3 * P, *hK = hw + 2 * P, *hur = hK + 9, *hvr = hur + 2, *hin = hvr + 2;
     memcpy(h2, pts2d, sizeof(double) * 2 * pn); memcpy(h3, pts3d, sizeof(double) * 3 * pn); memcpy(hw, wgt2d, sizeof(double) * 2 * pn);
-    for (int p = pn; p < P; ++p) h3[3 * p + 2] = 1.0;                     // padded points carry zero weight
+    for (int p = pn; p < P; ++p) { h2[2 * p] = h2[2 * p + 1] = 0.0; h3[3 * p] = h3[3 * p + 1] = 0.0; h3[3 * p + 2] = 1.0; hw[2 * p] = hw[2 * p + 1] = 0.0; }   // padded points carry zero weight
     memcpy(hK, K, sizeof(double) * 9);
     hur[0] = clips[1]; hur[1] = clips[2]; hvr[0] = clips[3]; hvr[1] = clips[4];
     memcpy(hin, init_pose, sizeof(double) * 4);
-    if (hipMemcpy(dbuf, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-    double *d = (double *)dbuf;
+    if (hipMemcpyAsync(d, h, nin * sizeof(double), hipMemcpyHostToDevice, sg->st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
     PnpArgs a;
     memset(&a, 0, sizeof a);
     a.x2d = d; a.x3d = d + 2 * P; a.istd = d + 5 * P;
@@ -738,21 +772,23 @@ void pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *
     a.K = d + 7 * P; a.K_stride = 0; a.K_f64 = 1;
     a.ur = d + 7 * P + 9; a.vr = d + 7 * P + 11; a.r_stride = 0; a.r_f64 = 1;
     a.init_pose = d + 7 * P + 13;
-    a.pose64 = d + 7 * P + 17; a.cov64 = d + 7 * P + 21; a.tr64 = d + 7 * P + 37;
-    float *df = (float *)(d + nd);
-    a.pose = df; a.cov = df + 4; a.tr = df + 20; a.valid = (uint8_t *)(df + 21);
+    double *dout = d + nin;
+    a.pose64 = dout; a.cov64 = dout + 4; a.tr64 = dout + 20; a.valid = (uint8_t *)(dout + 21);
+    float *df = (float *)(dout + nout);
+    a.pose = df; a.cov = df + 4; a.tr = df + 20;
     a.B = 1; a.P = P; a.z_min = clips[0]; a.istd_thres = 0.f; a.inlier_opt_only = 0;
     a.flags = MR_NO_ISTD_MASK | (result_cov ? MR_COV_CERES : MR_COV_NONE);
     a.mean_mode = MR_MEAN_SEQUENTIAL;
     int wpo = 1; while (wpo < 8 && P >= 64 * wpo * 2) wpo *= 2;
-    if (launch_wpo<double>(a, wpo, nullptr) != MR_OK) return;
-    std::vector<double> ho(21); uint8_t hv[16];
-    if (hipMemcpy(ho.data(), a.pose64, 21 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(hv, a.valid, 16, hipMemcpyDeviceToHost) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-    memcpy(result_pose, ho.data(), 4 * sizeof(double));
+    if (launch_wpo<double>(a, wpo, sg->st) != MR_OK) return;
+    double *ho = h + nin;
+    if (hipMemcpyAsync(ho, dout, nout * sizeof(double), hipMemcpyDeviceToHost, sg->st) != hipSuccess ||
+        hipStreamSynchronize(sg->st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
+    const uint8_t ok = *(const uint8_t *)(ho + 21);
+    memcpy(result_pose, ho, 4 * sizeof(double));
     *result_tr = ho[20];
-    *result_val = hv[0] ? 1 : 0;
-    if (hv[0] && result_cov) memcpy(result_cov, ho.data() + 4, 16 * sizeof(double));
+    *result_val = ok ? 1 : 0;
+    if (ok && result_cov) memcpy(result_cov, ho + 4, 16 * sizeof(double));
 }
 
 // The 7-parameter entry points of the reference's C ABI (ext.h:15-43).  Host fp64 buffers; one object; blocking.
@@ -762,20 +798,14 @@ static void noc_host(int full_cov, double *pts2d, double *pts3d, double *wgt2d, 
     memcpy(result_dimpose, init_dimpose, 7 * sizeof(double));            // pnp_uncert_cpu.cpp:309,351
     if (pn < 0) return;
     const int ws = full_cov ? 3 : 2;
-    // device staging: [pts2d 2n | pts3d 3n | wgt ws*n | logdim 3 | logdim_wgt 3 | K 9 | init 7 | clips 5 | out 7] doubles + val int
+    // staging, in doubles: [pts2d 2n | pts3d 3n | wgt ws*n | logdim 3 | logdim_wgt 3 | K 9 | init 7 | clips 5 || out 7 | val (int, 8 bytes)]
     const size_t n = (size_t)pn;
-    const size_t nd = (2 + 3 + ws) * n + 3 + 3 + 9 + 7 + 5 + 7;
-    const size_t bytes = nd * sizeof(double) + 16;
-    static std::mutex mu; static void *dbuf = nullptr; static size_t dcap = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (bytes > dcap) {
-        if (dbuf) (void)hipFree(dbuf);
-        dbuf = nullptr; dcap = 0;
-        if (hipMalloc(&dbuf, bytes) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-        dcap = bytes;
-    }
-    std::vector<double> h(nd, 0.0);
-    double *q = h.data();
+    const size_t nin = (2 + 3 + ws) * n + 3 + 3 + 9 + 7 + 5, nout = 7 + 1;
+    HostStage *sg = stage_acquire((nin + nout) * sizeof(double));
+    if (!sg) return;
+    std::lock_guard<std::mutex> lk(sg->mu, std::adopt_lock);
+    double *h = (double *)sg->hbuf, *d = (double *)sg->dbuf;
+    double *q = h;
     memcpy(q, pts2d, sizeof(double) * 2 * n); q += 2 * n;
     memcpy(q, pts3d, sizeof(double) * 3 * n); q += 3 * n;
     memcpy(q, wgt2d, sizeof(double) * ws * n); q += ws * n;
@@ -784,19 +814,18 @@ static void noc_host(int full_cov, double *pts2d, double *pts3d, double *wgt2d, 
     memcpy(q, K, sizeof(double) * 9); q += 9;
     memcpy(q, init_dimpose, sizeof(double) * 7); q += 7;
     memcpy(q, clips, sizeof(double) * 5);
-    if (hipMemcpy(dbuf, h.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-    double *d = (double *)dbuf;
+    if (hipMemcpyAsync(d, h, nin * sizeof(double), hipMemcpyHostToDevice, sg->st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
     NocArgs a;
     a.pts2d = d; a.pts3d = d + 2 * n; a.wgt2d = d + 5 * n; a.logdim = d + (5 + ws) * n; a.logdim_wgt = a.logdim + 3; a.K = a.logdim + 6;
-    a.init = a.logdim + 15; a.clips = a.logdim + 22; a.out_dimpose = (double *)(a.logdim + 27); a.out_val = (int *)(d + nd);
+    a.init = a.logdim + 15; a.clips = a.logdim + 22; a.out_dimpose = d + nin; a.out_val = (int *)(d + nin + 7);
     a.delta = delta; a.pn = pn; a.full_cov = full_cov;
-    hipLaunchKernelGGL(pnp_noc_kernel, dim3(1), dim3(256), sizeof(double) * 2 * 4 * kRedN, nullptr, a);
+    hipLaunchKernelGGL(pnp_noc_kernel, dim3(1), dim3(256), sizeof(double) * 2 * 4 * kRedN, sg->st, a);
     if (hipGetLastError() != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-    double ho[7]; int hv = 0;
-    if (hipMemcpy(ho, a.out_dimpose, sizeof ho, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&hv, a.out_val, sizeof hv, hipMemcpyDeviceToHost) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
-    memcpy(result_dimpose, ho, sizeof ho);
-    *result_val = hv;
+    double *ho = h + nin;
+    if (hipMemcpyAsync(ho, d + nin, nout * sizeof(double), hipMemcpyDeviceToHost, sg->st) != hipSuccess ||
+        hipStreamSynchronize(sg->st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
+    memcpy(result_dimpose, ho, 7 * sizeof(double));
+    *result_val = *(const int *)(ho + 7);
 }
 
 void pnp_noc_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,

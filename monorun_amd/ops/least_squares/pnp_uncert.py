@@ -72,7 +72,7 @@ class PnPLaunch:
 
     def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5,
                  epnp_istd_thres=0.6, epnp_ransac_thres=None, inlier_opt_only=True, init_pose=None, flags=0,
-                 out=None, with_diag=False):
+                 out=None, with_diag=False, mask=None):
         self.lib = _lib.load()
         dev = coords_2d.device
         if dev.type != 'cuda':
@@ -94,7 +94,8 @@ class PnPLaunch:
             self.tr = torch.empty(B, **f32)
         else:                                   # e.g. the typed views of parallel.PackedResults
             self.valid, self.pose, self.cov, self.tr = out.valid, out.pose, out.cov, out.tr
-        self.mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+        self.mask = mask if mask is not None else torch.empty(B, P, device=dev, dtype=torch.uint8)
+        assert self.mask.shape == (B, P) and self.mask.dtype == torch.uint8 and self.mask.is_contiguous()
         self.diag = torch.empty(B, 4, **f32) if with_diag else None
         self.B = B
         self.args = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d),

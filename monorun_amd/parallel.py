@@ -95,6 +95,8 @@ def _rccl():
     lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
     lib.ncclAllGather.restype = ctypes.c_int
     lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ncclCommCount.restype = ctypes.c_int
+    lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
     lib.ncclCommDestroy.restype = ctypes.c_int
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
     lib.ncclGetErrorString.restype = ctypes.c_char_p
@@ -133,6 +135,12 @@ class RcclAllGather:
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError(f'RCCL error {rc}: {self.lib.ncclGetErrorString(rc).decode()}')
+
+    def nranks(self):
+        """Number of ranks in the communicator as RCCL itself reports it (ncclCommCount)."""
+        n = ctypes.c_int(0)
+        self._check(self.lib.ncclCommCount(self.comm, ctypes.byref(n)))
+        return int(n.value)
 
     def gather(self, send, recv):
         assert send.dtype == torch.uint8 and recv.dtype == torch.uint8 and recv.numel() == self.world * send.numel()

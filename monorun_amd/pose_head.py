@@ -53,8 +53,22 @@ def _const(values, dev):
 _RANGE_CACHE = {}
 
 
+def _hw_rows(img_shapes):
+    """(n, 2) [H, W] rows from what the pipeline passes: a (H, W) or mmdet (H, W, 3) tuple of ONE image
+    (img_meta['img_shape']; the reference indexes only [:, 0] and [:, 1], uncert_prop_pnp_optimizer.py:75-80), or an
+    (n, 2) / (n, 3) array or tensor of per-image rows."""
+    if torch.is_tensor(img_shapes):
+        sh = img_shapes if img_shapes.dim() == 2 else img_shapes.reshape(1, -1)
+    else:
+        sh = np.asarray(img_shapes, np.float32)
+        sh = sh if sh.ndim == 2 else sh.reshape(1, -1)
+    assert sh.shape[1] in (2, 3), f'img_shape must be (H, W), (H, W, C) or rows of them, got shape {tuple(sh.shape)}'
+    return sh[:, :2]
+
+
 def _clip_ranges(img_shapes, allowed_border, dev):
     """u_range = [-border, W + border], v_range = [-border, H + border] (uncert_prop_pnp_optimizer.py:75-80)."""
+    img_shapes = _hw_rows(img_shapes)
     if torch.is_tensor(img_shapes) and img_shapes.device.type == 'cuda':
         sh = img_shapes.to(torch.float32).reshape(-1, 2)
         ur = sh.new_full((sh.size(0), 2), -float(allowed_border)); vr = ur.clone()
@@ -137,10 +151,7 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
     f32 = dict(device=dev, dtype=torch.float32)
     ap, ap_dt = _head_output(all_pred, dev)
     lab = labels.detach().to(device=dev, dtype=torch.int64).contiguous()
-    if isinstance(flip, bool):
-        fl = torch.full((B,), int(flip), device=dev, dtype=torch.uint8)
-    else:
-        fl = torch.as_tensor(flip, device=dev).to(torch.uint8).contiguous()
+    fl = _flip_flags(flip, B, dev)
     dm = dim.detach().to(**f32).contiguous()
     dv = dim_var.detach().to(**f32).contiguous() if dim_var is not None else None
     r = rois.detach().to(**f32)
@@ -243,7 +254,12 @@ _FLIP_CACHE = {}
 
 
 def _flip_flags(flip, B, dev):
-    """(B,) uint8 flip flags; the usual per-image bool becomes a cached constant tensor."""
+    """(B,) uint8 flip flags; the usual per-image bool (Python / numpy bool or a 0-dim / 1-element tensor or array, as
+    img_meta['flip'] arrives) becomes a cached constant tensor; anything else must hold exactly B flags."""
+    if torch.is_tensor(flip) and flip.numel() == 1 and B != 1:
+        flip = bool(flip.item())
+    elif isinstance(flip, np.ndarray) and flip.size == 1 and B != 1:
+        flip = bool(flip.reshape(()))
     if isinstance(flip, (bool, np.bool_)):
         key = (str(dev), bool(flip), B)
         t = _FLIP_CACHE.get(key)
@@ -253,7 +269,9 @@ def _flip_flags(flip, B, dev):
             t = torch.full((max(B, 1),), int(flip), device=dev, dtype=torch.uint8)
             _FLIP_CACHE[key] = t
         return t
-    return torch.as_tensor(flip, device=dev).to(torch.uint8).contiguous()
+    fl = torch.as_tensor(flip, device=dev).to(torch.uint8).reshape(-1).contiguous()
+    assert fl.numel() == B, f'flip must be a bool or hold one flag per object ({B}), got {fl.numel()}'
+    return fl
 
 
 def _planar_view(x):
@@ -347,7 +365,7 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
     else:
         dec = noc_decode(all_pred, labels, flip, dim, dim_var, rois, std_scale=pose_head.std_scale,
                          epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, **decode_kw)
-        img_shapes = torch.as_tensor(img_shape, device=all_pred.device, dtype=torch.float32).reshape(-1, 2)
+        img_shapes = torch.as_tensor(np.asarray(_hw_rows(img_shape.cpu() if torch.is_tensor(img_shape) else img_shape), np.float32), device=all_pred.device)
         ret_val, yaw, t_vec, cov, cov_calib = pose_head.forward_decoded(dec, cam_intrinsic, img_shapes)
         dims, dims_var = dec['dims'], dec['dims_var']
     if apply_cov_correction:

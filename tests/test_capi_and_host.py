@@ -127,3 +127,25 @@ def test_capi_argument_validation_without_a_gpu():
     assert lib.mr_nms_bev_batched(None, None, None, 0, 0, 0.1, None, None, None) == 0
     assert lib.mr_nms_bev_batched(p, p, p, 1, 4096, 0.1, p, p, None) == -2
     assert lib.mr_nms_bev_batched(p, p, None, 1, 8, 0.1, p, p, None) == -1
+
+
+def test_img_shape_and_flip_forms_the_pipeline_passes():
+    """mmdet hands img_meta['img_shape'] = (H, W, 3) and a per-image bool flip (Python or numpy bool, or a 0-dim tensor):
+    the host glue takes the first two entries per image like the reference (uncert_prop_pnp_optimizer.py:75-80) and turns
+    every scalar flip form into B flags (one flag per object otherwise; a wrong count is refused, not read out of bounds)."""
+    from monorun_amd import pose_head as ph
+    cpu = torch.device('cpu')
+    for shp in ((375, 1242), (375, 1242, 3), [[375, 1242, 3]], np.array([[375., 1242.]]), torch.tensor([[375., 1242., 3.]])):
+        ur, vr = ph._clip_ranges(shp, 200, cpu)
+        assert ur.tolist() == [[-200.0, 1442.0]] and vr.tolist() == [[-200.0, 575.0]]
+    ur, vr = ph._clip_ranges(((375, 1242, 3), (370, 1224, 3)), 200, cpu)
+    assert ur.tolist() == [[-200.0, 1442.0], [-200.0, 1424.0]] and vr.tolist() == [[-200.0, 575.0], [-200.0, 570.0]]
+    with pytest.raises(AssertionError):
+        ph._clip_ranges((375, 1242, 3, 1), 200, cpu)
+    for f in (True, np.bool_(True), torch.tensor(True), np.array(True), np.array([True])):
+        fl = ph._flip_flags(f, 5, cpu)
+        assert fl.dtype == torch.uint8 and fl.tolist() == [1] * 5
+    assert ph._flip_flags([True, False, True], 3, cpu).tolist() == [1, 0, 1]
+    assert ph._flip_flags(torch.tensor([False]), 1, cpu).tolist() == [0]
+    with pytest.raises(AssertionError):
+        ph._flip_flags([True, False], 3, cpu)

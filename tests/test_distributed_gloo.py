@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo run of the sharding + single packed all-gather
-(monorun_amd/parallel.py).  The per-shard solve is a stand-in (the CPU oracle — tests may use it;
-the product's solve needs an MI355X), what is under test is shard bounds, packing and the exchange."""
+"""N>1 path on CPU: gloo runs (world sizes 2, 4, 8; even, uneven and empty shards) of the sharding + single packed
+all-gather (monorun_amd/parallel.py), and of the rank launcher (monorun_amd/launch.py).  On CPU the per-shard solve is a
+stand-in (the CPU oracle — tests may use it; the product's solve needs an MI355X): what is under test is shard bounds,
+packing, the exchange and the launcher.  The `-m gpu` tests at the bottom run the same `sharded_pnp` with the HIP solve
+inside an nccl (RCCL) job and bench.py's self-launch."""
 import os
 import socket
 import sys
@@ -47,26 +49,28 @@ def _worker(rank, world, port, n_objects, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_objects', [10, 7])
-def test_two_rank_sharded_solve_equals_single_process(n_objects):
+@pytest.mark.parametrize('world,n_objects', [(2, 10), (2, 7), (4, 10), (4, 3), (8, 13), (8, 5)])
+def test_sharded_solve_equals_single_process(world, n_objects):
+    """even shards, uneven shards (last rank short) and ranks whose shard is empty (4 ranks x 3 objects, 8 x 5)."""
     from monorun_amd import synthetic as syn
+    from monorun_amd.parallel import shard_bounds
     from oracle import oracle as orc
-    world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_objects, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     b = syn.make_batch(B=n_objects, seed=321)
     x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=False)
     ret, yaw, t, cov, tr, mask = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True)
     res.sort(key=lambda r: r[0])
-    assert [(r[1], r[2]) for r in res] == [(0, (n_objects + 1) // 2), ((n_objects + 1) // 2, n_objects)]
+    assert [(r[1], r[2]) for r in res] == [shard_bounds(n_objects, r, world)[:2] for r in range(world)]
+    assert sum(r[2] - r[1] for r in res) == n_objects
     for rank, lo, hi, per, out in res:                     # every rank ends up with the full, ordered result
         assert out['pose'].shape == (n_objects, 4) and out['cov'].shape == (n_objects, 4, 4)
         assert np.array_equal(out['pose'], np.concatenate([yaw, t], 1))
@@ -90,6 +94,86 @@ def test_shard_bounds_cover_everything_once():
     assert (u['pose'] == 1.5).all() and (u['cov'] == 2.5).all() and (u['tr'] == 3.5).all() and u['valid'].all()
 
 
+def test_launcher_starts_n_ranks_and_refuses_without_devices(tmp_path):
+    """monorun_amd.launch: `spawn_ranks` starts N ranks through torch.distributed.run on 127.0.0.1 (each sees RANK /
+    WORLD_SIZE / LOCAL_RANK and can rendezvous), and refuses with a clear message when N exceeds the visible devices."""
+    import subprocess
+    from monorun_amd import launch
+    script = tmp_path / 'ranks.py'
+    script.write_text(
+        'import os, sys, torch, torch.distributed as dist\n'
+        'dist.init_process_group("gloo")\n'
+        't = torch.tensor([float(dist.get_rank() + 1)])\n'
+        'dist.all_reduce(t)\n'
+        'open(os.path.join(sys.argv[1], "rank%d" % dist.get_rank()), "w").write("%d %d %s %g" % (dist.get_world_size(), int(os.environ["LOCAL_RANK"]), os.environ["MASTER_ADDR"], t.item()))\n'
+        'dist.destroy_process_group()\n')
+    assert not launch.in_distributed_job()
+    rc = launch.spawn_ranks(3, str(script), [str(tmp_path)], need_devices=False)
+    assert rc == 0
+    for r in range(3):
+        assert (tmp_path / f'rank{r}').read_text() == f'3 {r} 127.0.0.1 6'
+    cmd = launch.launch_command(8, str(script), ['--x'], port=1234)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd and cmd[-1] == '--x'
+    if launch.visible_devices() < 8:
+        with pytest.raises(SystemExit) as e:
+            launch.spawn_ranks(8, str(script), [str(tmp_path)])
+        assert 'needs 8 visible MI355X devices' in str(e.value)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and 'needs 8 visible MI355X devices' in r.stderr
+
+
+@pytest.mark.gpu
+def test_sharded_pnp_with_the_hip_solve_in_an_nccl_job():
+    """parallel.sharded_pnp with the PRODUCT's per-shard solve (the HIP kernel writing straight into PackedResults) inside
+    an nccl (= RCCL) torch.distributed job — world size 1 is all a 1-GPU box offers — compared with a plain launch."""
+    import subprocess, textwrap
+    code = textwrap.dedent('''
+        import os, sys, numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, ROOT_DIR)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29573')
+        torch.cuda.set_device(0); dev = torch.device('cuda', 0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        from monorun_amd import synthetic as syn, PnPLaunch
+        from monorun_amd.parallel import sharded_pnp
+        b = syn.make_batch(B=37, seed=99)
+        x2d, istd, x3d, K, ur, vr, thr = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in syn.pnp_boundary(b, planar=False)]
+        def solve(lo, hi, packed):
+            PnPLaunch(x2d[lo:hi], istd[lo:hi], x3d[lo:hi], K, ur, vr, epnp_ransac_thres=thr[lo:hi], out=packed).run()
+        out = sharded_pnp(solve, 37, dev)
+        ref = PnPLaunch(x2d, istd, x3d, K, ur, vr, epnp_ransac_thres=thr); ref.run(); torch.cuda.synchronize()
+        assert out['pose'].shape == (37, 4) and torch.equal(out['pose'], ref.pose) and torch.equal(out['cov'], ref.cov)
+        assert torch.equal(out['valid'], ref.valid.bool()) and torch.equal(out['tr'], ref.tr) and int(out['valid'].sum()) >= 35
+        dist.destroy_process_group(); print('SHARDED_HIP_OK')
+    ''').replace('ROOT_DIR', repr(ROOT))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert 'SHARDED_HIP_OK' in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` starts its own two ranks.  On a 1-GPU box RCCL refuses two ranks on one device, so the
+    test mode MR_BENCH_OVERSUBSCRIBE=1 shares the GPU and exchanges through gloo — launcher, rank environment, per-rank
+    batches, max-over-ranks timing and the JSON line (n_gpus, comm block) are the real code path; without the override the
+    script refuses with a device-count message.  With >= 2 devices the RCCL path itself runs."""
+    import json, subprocess, torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ndev < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1'],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and 'needs 2 visible MI355X devices' in r.stderr
+        env['MR_BENCH_OVERSUBSCRIBE'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--batches', '2',
+                        '--no-cpu-baseline', '--no-secondary'], capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['comm']['nranks'] == 2 and line['comm']['bytes_per_rank'] == 88 * 1024
+    assert line['comm']['gathered_rows_verified'] is True and line['value'] > 0 and line['scaling'] == 'weak'
+    assert ('rccl' in line['comm']['backend']) == (ndev >= 2)
+
+
 @pytest.mark.gpu
 def test_direct_rccl_all_gather_world_size_1():
     """parallel.RcclAllGather (private RCCL communicator, ncclAllGather on a side stream) inside a 1-rank nccl job — the only
@@ -103,6 +187,7 @@ def test_direct_rccl_all_gather_world_size_1():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         from monorun_amd.parallel import RcclAllGather, PackedResults
         ag = RcclAllGather(dev)
+        assert ag.nranks() == 1
         pk = PackedResults(100, dev)
         out = torch.zeros(pk.buf.numel(), dtype=torch.uint8, device=dev)
         for it in range(3):
