@@ -34,8 +34,8 @@ c_ip = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     so = os.path.join(_HERE, 'libpnp_oracle.so')
-    src = os.path.join(_HERE, 'pnp_oracle.c')
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ('pnp_oracle.c', 'epnp.inc', 'jet.inc', 'Makefile')]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'libpnp_oracle.so'],
                               stdout=subprocess.DEVNULL)
     return so
@@ -48,6 +48,7 @@ def lib():
         _LIB.orc_max_threads.restype = ctypes.c_int
         _LIB.orc_k0_init.restype = ctypes.c_int
         _LIB.orc_pose_cov.restype = ctypes.c_int
+        _LIB.orc_epnp_ransac.restype = ctypes.c_int
     return _LIB
 
 
@@ -135,15 +136,18 @@ def istd_inlier_mask(coords_2d_istd, epnp_istd_thres):
 
 def u2d_pnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5,
             epnp_istd_thres=1.0, epnp_ransac_thres=None, inlier_opt_only=False,
-            init_pose=None, n_hyp=32, num_threads=1, return_diag=False):
+            init_pose=None, n_hyp=32, num_threads=1, return_diag=False, init_mode=0, return_init=False):
     """R4+R5+R6 for a batch (the numpy-level driver).  Returns the reference's 6-tuple
-    (ret_val, yaw, t_vec, pose_cov, tr_radius, inlier_mask) [+ diag]; pose_cov is the
-    torch-semantics inverse(J^T J) that pnp_uncert.py:71-85 computes."""
+    (ret_val, yaw, t_vec, pose_cov, tr_radius, inlier_mask) [+ diag] [+ init (B,4) fp64]; pose_cov is the
+    torch-semantics inverse(J^T J) that pnp_uncert.py:71-85 computes.
+    init_mode 0: K0 (this repo's consensus initialiser, what the HIP kernel runs); 1: the reference's own initialiser
+    restated (EPnP inside OpenCV's RANSAC loop, oracle/epnp.inc)."""
     B, P = coords_2d.shape[:2]
     if B == 0:
         out = (np.zeros((0,), bool), np.zeros((0, 1), np.float32), np.zeros((0, 3), np.float32),
                np.zeros((0, 4, 4), np.float32), np.zeros((0, 1), np.float32), np.zeros((0, P), bool))
-        return out + (np.zeros((0, 4), np.float32),) if return_diag else out
+        out = out + (np.zeros((0, 4), np.float32),) if return_diag else out
+        return out + (np.zeros((0, 4)),) if return_init else out
     assert coords_2d_istd.shape[1] == coords_3d.shape[1] == P >= 4
     mask = np.ascontiguousarray(istd_inlier_mask(coords_2d_istd, epnp_istd_thres), np.uint8)
     x2d, istd, x3d = _f(coords_2d), _f(coords_2d_istd), _f(coords_3d)
@@ -157,14 +161,65 @@ def u2d_pnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_
     cov = np.zeros((B, 16), np.float32)
     tr = np.zeros(B, np.float32)
     diag = np.zeros((B, 4), np.float32)
-    lib().orc_u2d_pnp_batch(_p(x2d, c_fp), _p(istd, c_fp), _p(x3d, c_fp), _p(K, c_fp), ctypes.c_int(K.shape[0]),
-                            _p(ur, c_fp), _p(vr, c_fp), ctypes.c_int(ur.shape[0]), _p(thr, c_fp), _p(ini, c_dp),
-                            ctypes.c_int(B), ctypes.c_int(P), ctypes.c_double(z_min), ctypes.c_int(bool(inlier_opt_only)),
-                            ctypes.c_int(n_hyp), ctypes.c_int(num_threads), _p(mask, c_u8p), _p(valid, c_u8p),
-                            _p(pose, c_fp), _p(cov, c_fp), _p(tr, c_fp), _p(diag, c_fp))
+    init_out = np.zeros((B, 4))
+    lib().orc_u2d_pnp_batch_ex(_p(x2d, c_fp), _p(istd, c_fp), _p(x3d, c_fp), _p(K, c_fp), ctypes.c_int(K.shape[0]),
+                               _p(ur, c_fp), _p(vr, c_fp), ctypes.c_int(ur.shape[0]), _p(thr, c_fp), _p(ini, c_dp),
+                               ctypes.c_int(B), ctypes.c_int(P), ctypes.c_double(z_min), ctypes.c_int(bool(inlier_opt_only)),
+                               ctypes.c_int(n_hyp), ctypes.c_int(init_mode), ctypes.c_int(num_threads), _p(mask, c_u8p), _p(valid, c_u8p),
+                               _p(pose, c_fp), _p(cov, c_fp), _p(tr, c_fp), _p(diag, c_fp), _p(init_out, c_dp))
     out = (valid.astype(bool), pose[:, :1].copy(), pose[:, 1:].copy(), cov.reshape(B, 4, 4),
            tr[:, None].copy(), mask.astype(bool))
-    return out + (diag,) if return_diag else out
+    out = out + (diag,) if return_diag else out
+    return out + (init_out,) if return_init else out
+
+
+def u2d_pnp_epnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
+                 epnp_ransac_thres=None, inlier_opt_only=False, **kw):
+    """The reference's flow with its OWN initialiser restated (cv2.solvePnPRansac / solvePnP with SOLVEPNP_EPNP,
+    pnp_uncert_cpu.py:35-58) in front of the same LM and covariance: the comparison point for K0."""
+    return u2d_pnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min, epnp_istd_thres, epnp_ransac_thres,
+                   inlier_opt_only, init_mode=1, **kw)
+
+
+def epnp(obj, img, K):
+    """cv2.solvePnP(obj, img, K, 0, flags=SOLVEPNP_EPNP) restated: returns (rvec (3,), tvec (3,), R (3,3))."""
+    obj, img, K = _f(obj), _f(img), _f(K).reshape(9)
+    rvec, tvec, R = np.zeros(3), np.zeros(3), np.zeros(9)
+    lib().orc_epnp(_p(obj, c_fp), _p(img, c_fp), ctypes.c_int(obj.shape[0]), _p(K, c_fp), _p(rvec, c_dp), _p(tvec, c_dp), _p(R, c_dp))
+    return rvec, tvec, R.reshape(3, 3)
+
+
+def epnp_ransac(obj, img, K, thr, max_iters=30):
+    """cv2.solvePnPRansac(obj, img, K, 0, reprojectionError=thr, iterationsCount=max_iters, flags=SOLVEPNP_EPNP) restated:
+    returns dict(ok, rvec, tvec, mask (n,) bool, iters)."""
+    obj, img, K = _f(obj), _f(img), _f(K).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    mask = np.zeros(obj.shape[0], np.uint8)
+    it = np.zeros(1, np.int32)
+    ok = lib().orc_epnp_ransac(_p(obj, c_fp), _p(img, c_fp), ctypes.c_int(obj.shape[0]), _p(K, c_fp), ctypes.c_float(thr), ctypes.c_int(max_iters),
+                               _p(rvec, c_dp), _p(tvec, c_dp), _p(mask, c_u8p), _p(it, c_ip))
+    return dict(ok=bool(ok), rvec=rvec, tvec=tvec, mask=mask.astype(bool), iters=int(it[0]))
+
+
+def eig_sym(A):
+    A = _d(A); n = A.shape[0]
+    w, vt = np.zeros(n), np.zeros((n, n))
+    lib().orc_eig_sym(ctypes.c_int(n), _p(A, c_dp), _p(w, c_dp), _p(vt, c_dp))
+    return w, vt
+
+
+def svd_small(A):
+    A = _d(A); m, n = A.shape
+    w, u, v = np.zeros(n), np.zeros((m, n)), np.zeros((n, n))
+    lib().orc_svd_small(ctypes.c_int(m), ctypes.c_int(n), _p(A, c_dp), _p(w, c_dp), _p(u, c_dp), _p(v, c_dp))
+    return w, u, v
+
+
+def cv_rng_uniform(seed, count, a, b):
+    """`count` draws of cv::RNG(seed).uniform(a, b) (the generator RANSAC samples its subsets with)."""
+    out = np.zeros(count, np.int32)
+    lib().orc_cv_rng(ctypes.c_uint64(seed), ctypes.c_int(count), ctypes.c_int(a), ctypes.c_int(b), _p(out, c_ip))
+    return out
 
 
 def max_threads():

@@ -631,6 +631,33 @@ int orc_k0_init(const float *x2d /*pn,2*/, const float *x3d /*pn,3*/, uint8_t *m
     return ok;
 }
 
+#include "epnp.inc"     /* the reference's own initialiser restated: EPnP inside OpenCV's RANSAC loop */
+
+/* the reference's initialiser on the candidate subset (pnp_uncert_cpu.py:34-58): EPnP/RANSAC when a threshold is given
+ * (the mask is narrowed to the RANSAC inliers when more than 4 come back), plain EPnP otherwise; yaw0 = r_vec[1] (:68) */
+static int orc_epnp_init(const float *x2d, const float *x3d, uint8_t *mask, int pn, const float *K, int use_ransac, float thr,
+                         double init_pose[4], int *count) {
+    int n = 0; for (int p = 0; p < pn; ++p) n += mask[p] ? 1 : 0;
+    float *o = (float *)calloc(5 * (size_t)(n > 0 ? n : 1), sizeof(float)); float *im = o + 3 * (size_t)n;
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); uint8_t *rm = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    int m = 0;
+    for (int p = 0; p < pn; ++p) if (mask[p]) { idx[m] = p; o[3 * m] = x3d[3 * p]; o[3 * m + 1] = x3d[3 * p + 1]; o[3 * m + 2] = x3d[3 * p + 2];
+                                                im[2 * m] = x2d[2 * p]; im[2 * m + 1] = x2d[2 * p + 1]; ++m; }
+    double rvec[3], tvec[3], R[9]; int ok;
+    if (use_ransac) {
+        ok = epnp_solve_ransac(o, im, n, K, thr, 30, rvec, tvec, rm, NULL);
+        int ninl = 0; if (ok) for (int i = 0; i < n; ++i) ninl += rm[i];
+        if (ok && ninl > 4) { for (int i = 0; i < n; ++i) mask[idx[i]] = rm[i]; n = ninl; }
+    } else if (n >= 4) {
+        epnp_solve(o, im, n, K[0], K[4], K[2], K[5], R, tvec); epnp_rodrigues_to_vec(R, rvec); ok = 1;
+    } else ok = 0;
+    if (ok) { init_pose[0] = rvec[1]; init_pose[1] = tvec[0]; init_pose[2] = tvec[1]; init_pose[3] = tvec[2];
+              ok = isfinite(init_pose[0]) && isfinite(init_pose[1]) && isfinite(init_pose[2]) && isfinite(init_pose[3]); }
+    if (count) *count = n;
+    free(o); free(idx); free(rm);
+    return ok;
+}
+
 /* ------------------------------------------------------------------------------------------
  * R5 + R6 for a batch: per object  mask0 -> (count>4 ? subset : all) -> K0 (or given init) ->
  * LM on inliers (inlier_opt_only) -> float32 pose -> torch-semantics J^T J on ALL points masked by
@@ -640,13 +667,15 @@ int orc_k0_init(const float *x2d /*pn,2*/, const float *x3d /*pn,3*/, uint8_t *m
  * ---------------------------------------------------------------------------------------- */
 static void orc_one_object(const float *x2d, const float *istd, const float *x3d, const float *K,
                            const float *ur, const float *vr, const float *thr, const double *init,
-                           int pn, double z_min, int inlier_opt_only, int n_hyp,
-                           uint8_t *mask, uint8_t *valid, float *pose, float *cov, float *tr, float *diag) {
+                           int pn, double z_min, int inlier_opt_only, int n_hyp, int init_mode /* 0 = K0, 1 = EPnP/RANSAC restatement */,
+                           uint8_t *mask, uint8_t *valid, float *pose, float *cov, float *tr, float *diag, double *init_out /* nullable 4 */) {
     int cnt = 0; for (int p = 0; p < pn; ++p) cnt += mask[p] ? 1 : 0;
     if (!(cnt > 4)) { for (int p = 0; p < pn; ++p) mask[p] = 1; }                       /* pnp_uncert_cpu.py:23-32 */
     double init_pose[4] = {0, 0, 0, 0}; int ok, bh = -1, bc = 0;
     if (init) { memcpy(init_pose, init, sizeof init_pose); ok = 1; for (int p = 0; p < pn; ++p) bc += mask[p] ? 1 : 0; }
+    else if (init_mode == 1) ok = orc_epnp_init(x2d, x3d, mask, pn, K, thr != NULL, thr ? *thr : 0.0f, init_pose, &bc);
     else ok = orc_k0_init(x2d, x3d, mask, pn, K, thr != NULL, thr ? *thr : 0.0f, n_hyp, init_pose, &bh, &bc);
+    if (init_out) for (int j = 0; j < 4; ++j) init_out[j] = ok ? init_pose[j] : 0.0;
     double res_pose[4] = {0, 0, 0, 0}, res_tr = 0.0; int res_val = 0; double dg[6] = {0, 0, 0, 0, 0, 0};
     if (ok) {
         /* gather what LM sees, cast to float64 (pnp_uncert_cpu.py:62-81) */
@@ -680,12 +709,12 @@ static void orc_one_object(const float *x2d, const float *istd, const float *x3d
     }
 }
 
-void orc_u2d_pnp_batch(const float *x2d, const float *istd, const float *x3d,
-                       const float *K, int Kb, const float *u_range, const float *v_range, int Rb,
-                       const float *ransac_thr /*nullable (B)*/, const double *init_pose /*nullable (B,4)*/,
-                       int B, int P, double z_min, int inlier_opt_only, int n_hyp, int num_threads,
-                       uint8_t *mask /*B,P in/out*/, uint8_t *valid /*B*/, float *pose /*B,4*/,
-                       float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/) {
+void orc_u2d_pnp_batch_ex(const float *x2d, const float *istd, const float *x3d,
+                          const float *K, int Kb, const float *u_range, const float *v_range, int Rb,
+                          const float *ransac_thr /*nullable (B)*/, const double *init_pose /*nullable (B,4)*/,
+                          int B, int P, double z_min, int inlier_opt_only, int n_hyp, int init_mode, int num_threads,
+                          uint8_t *mask /*B,P in/out*/, uint8_t *valid /*B*/, float *pose /*B,4*/,
+                          float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/, double *init_out /*nullable B,4*/) {
 #ifdef _OPENMP
     if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel for schedule(dynamic, 4) if (num_threads != 1)
@@ -694,9 +723,20 @@ void orc_u2d_pnp_batch(const float *x2d, const float *istd, const float *x3d,
         orc_one_object(x2d + (size_t)b * P * 2, istd + (size_t)b * P * 2, x3d + (size_t)b * P * 3,
                        K + (Kb == 1 ? 0 : (size_t)b * 9), u_range + (Rb == 1 ? 0 : (size_t)b * 2), v_range + (Rb == 1 ? 0 : (size_t)b * 2),
                        ransac_thr ? ransac_thr + b : NULL, init_pose ? init_pose + (size_t)b * 4 : NULL,
-                       P, z_min, inlier_opt_only, n_hyp,
-                       mask + (size_t)b * P, valid + b, pose + (size_t)b * 4, cov + (size_t)b * 16, tr + b, diag ? diag + (size_t)b * 4 : NULL);
+                       P, z_min, inlier_opt_only, n_hyp, init_mode,
+                       mask + (size_t)b * P, valid + b, pose + (size_t)b * 4, cov + (size_t)b * 16, tr + b, diag ? diag + (size_t)b * 4 : NULL,
+                       init_out ? init_out + (size_t)b * 4 : NULL);
     }
+}
+
+void orc_u2d_pnp_batch(const float *x2d, const float *istd, const float *x3d,
+                       const float *K, int Kb, const float *u_range, const float *v_range, int Rb,
+                       const float *ransac_thr /*nullable (B)*/, const double *init_pose /*nullable (B,4)*/,
+                       int B, int P, double z_min, int inlier_opt_only, int n_hyp, int num_threads,
+                       uint8_t *mask /*B,P in/out*/, uint8_t *valid /*B*/, float *pose /*B,4*/,
+                       float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/) {
+    orc_u2d_pnp_batch_ex(x2d, istd, x3d, K, Kb, u_range, v_range, Rb, ransac_thr, init_pose, B, P, z_min, inlier_opt_only, n_hyp, 0,
+                         num_threads, mask, valid, pose, cov, tr, diag, NULL);
 }
 
 int orc_max_threads(void) {

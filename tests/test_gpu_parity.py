@@ -391,3 +391,22 @@ def test_adversarial_inputs_terminate_and_match_oracle_validity(dev, orc):
             valid, pose = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy()
             assert np.isfinite(pose[valid]).all(), (trial, mode, wpo)
             assert np.array_equal(valid, ref[0]), (trial, mode, wpo)
+
+
+def test_hip_kernel_against_the_reference_initialiser_restated(dev, orc):
+    """R5: the HIP kernel (K0 initialiser) against the reference's flow with its OWN initialiser restated (EPnP inside
+    OpenCV's RANSAC loop, oracle/epnp.inc) on a config-2 batch, compared after the LM: same validity, the same inlier set
+    for the large majority of objects, poses within a small fraction of the posterior standard deviation
+    (distribution: DESIGN.md §5; CPU counterpart: tests/test_oracle_epnp.py)."""
+    from test_oracle_epnp import compare_runs
+    b = syn.make_batch(B=512, seed=1234)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    valid, pose, cov, tr, mask, diag = _run(dev, x2d, istd, x3d, K, ur, vr, thr)
+    c = [np.ascontiguousarray(a) for a in (x2d, istd, x3d)]
+    ref = orc.u2d_pnp_epnp(c[0], c[1], c[2], K, ur, vr, 0.5, 0.6, thr, True, num_threads=0)
+    s = compare_runs((valid, pose[:, :1], pose[:, 1:], cov, tr, mask), ref)
+    assert s['valid0'].all() and s['valid1'].all()
+    assert s['same'].mean() >= 0.80 and s['iou'].mean() >= 0.995 and s['iou'].min() >= 0.80
+    sm, df = s['same'] & s['ok'], ~s['same'] & s['ok']
+    assert np.nanquantile(s['maha'][sm], 0.99) <= 0.05 and np.mean(s['maha'][sm] > 0.1) <= 0.01
+    assert np.nanmax(s["maha"][df]) <= 5.0 and np.nanquantile(s['maha'][df], 0.5) <= 0.1

@@ -1,0 +1,160 @@
+"""The reference's initialiser restated (oracle/epnp.inc: EPnP inside OpenCV's RANSAC loop, pnp_uncert_cpu.py:35-58) —
+OpenCV itself is absent, so the restatement is pinned by known answers and numpy cross-checks, and then used as the
+comparison point for K0 (this repo's initialiser, what the HIP kernel runs): inlier-set overlap and post-LM pose agreement
+on config-2 data, with the thresholds of the distribution recorded in DESIGN.md §5."""
+import numpy as np
+import pytest
+
+from monorun_amd import synthetic as syn
+
+K = np.array([[707.0912, 0, 601.8873], [0, 707.0912, 183.1104], [0, 0, 1]], np.float32)
+
+
+def _rodrigues(r):
+    th = np.linalg.norm(r)
+    if th < 1e-12:
+        return np.eye(3)
+    k = r / th
+    kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * kx + (1 - np.cos(th)) * kx @ kx
+
+
+def _project(X, R, t):
+    xc = X.astype(np.float64) @ R.T + t
+    return (xc[:, :2] / xc[:, 2:]) * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+
+
+def test_linear_algebra_kernels_against_numpy(orc):
+    rng = np.random.default_rng(0)
+    for n in (3, 12):
+        a = rng.normal(size=(40, n))
+        s = a.T @ a
+        w, vt = orc.eig_sym(s)
+        w_np, v_np = np.linalg.eigh(s)
+        assert np.abs(w - w_np[::-1]).max() <= 1e-12 * w_np.max()
+        assert np.abs(np.abs(vt @ v_np[:, ::-1]) - np.eye(n)).max() <= 1e-10          # same eigenvectors up to sign
+        assert np.abs(vt @ vt.T - np.eye(n)).max() <= 1e-13
+    # rank-deficient 12x12 (what 5 correspondences give: rank 10): the last two rows span the null space
+    a = rng.normal(size=(10, 12))
+    s = a.T @ a
+    w, vt = orc.eig_sym(s)
+    assert w[10] <= 1e-12 * w[0] and np.abs(s @ vt[10:].T).max() <= 1e-11 * w[0]
+    for m, n in ((3, 3), (6, 3), (6, 4), (6, 5)):
+        a = rng.normal(size=(m, n))
+        w, u, v = orc.svd_small(a)
+        assert np.abs(u @ np.diag(w) @ v.T - a).max() <= 1e-14 and np.abs(w - np.linalg.svd(a)[1]).max() <= 1e-14
+        assert np.all(np.diff(w) <= 0)
+
+
+def test_cv_rng_is_the_published_multiply_with_carry_generator(orc):
+    """cv::RNG: state = (uint32)state * 4164903690 + (state >> 32), next() = (uint32)state, uniform(a,b) = next() % (b-a) + a;
+    RANSAC seeds it with (uint64)-1 (ptsetreg.cpp).  Independent Python restatement of the same recurrence."""
+    def py(seed, count, a, b):
+        state, out = (seed or 0xffffffff), []
+        for _ in range(count):
+            state = ((state & 0xffffffff) * 4164903690 + (state >> 32)) & 0xffffffffffffffff
+            out.append((state & 0xffffffff) % (b - a) + a)
+        return out
+    for seed, a, b in ((2**64 - 1, 0, 600), (2**64 - 1, 0, 5), (12345, 3, 11), (0, 0, 1000)):
+        assert orc.cv_rng_uniform(seed, 64, a, b).tolist() == py(seed, 64, a, b)
+
+
+@pytest.mark.parametrize('n,tol', [(5, 2e-4), (6, 2e-4), (8, 2e-4), (100, 1e-5), (600, 5e-6)])
+def test_epnp_recovers_noise_free_6dof_poses(orc, n, tol):
+    """known answer: exact projections (stored as float32, as the pipeline hands them over) of a general 6-DoF pose;
+    n = 5 is RANSAC's minimal sample (rank-10 system, two-dimensional null space)."""
+    rng = np.random.default_rng(n)
+    worst = 0.0
+    for _ in range(25):
+        R = _rodrigues(rng.normal(size=3) * 0.8)
+        t = np.array([rng.uniform(-5, 5), rng.uniform(-1, 2), rng.uniform(8, 40)])
+        X = (rng.uniform(-1, 1, (n, 3)) * np.array([2, 0.8, 0.9])).astype(np.float32)
+        rvec, tvec, Rr = orc.epnp(X, _project(X, R, t).astype(np.float32), K)
+        worst = max(worst, np.abs(Rr - R).max(), np.abs(tvec - t).max() / np.abs(t).max())
+        assert np.abs(_rodrigues(rvec) - Rr).max() <= 1e-12                           # Rodrigues round trip
+    assert worst <= tol
+
+
+def test_epnp_yaw_is_the_y_component_of_the_rotation_vector(orc):
+    """the reference takes yaw0 = r_vec[1] (pnp_uncert_cpu.py:68): for a pure yaw rotation that IS the yaw."""
+    rng = np.random.default_rng(3)
+    for yaw in (-2.5, -0.3, 0.0, 0.9, 3.0):
+        c, s = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        t = np.array([1.0, 1.5, 15.0])
+        X = (rng.uniform(-1, 1, (64, 3)) * np.array([2, 0.8, 0.9])).astype(np.float32)
+        rvec, tvec, _ = orc.epnp(X, _project(X, R, t).astype(np.float32), K)
+        assert abs(rvec[1] - yaw) <= 1e-5 and abs(rvec[0]) <= 1e-5 and abs(rvec[2]) <= 1e-5 and np.abs(tvec - t).max() <= 1e-4
+
+
+def test_ransac_separates_gross_outliers_and_stops_early(orc):
+    rng = np.random.default_rng(11)
+    R = _rodrigues(np.array([0.02, 0.7, -0.01]))
+    t = np.array([2.0, 1.4, 20.0])
+    n = 500
+    X = (rng.uniform(-1, 1, (n, 3)) * np.array([2, 0.8, 0.9])).astype(np.float32)
+    uv = _project(X, R, t) + rng.normal(0, 0.3, (n, 2))
+    bad = rng.uniform(size=n) < 0.2
+    uv[bad] += rng.uniform(20, 60, (bad.sum(), 2)) * rng.choice([-1, 1], (bad.sum(), 2))
+    out = orc.epnp_ransac(X, uv.astype(np.float32), K, thr=3.0)
+    assert out['ok'] and 1 <= out['iters'] <= 30
+    assert not out['mask'][bad].any() and out['mask'][~bad].mean() >= 0.98
+    assert np.abs(out['tvec'] - t).max() <= 0.2 and abs(out['rvec'][1] - 0.7) <= 0.02
+    assert out['iters'] < 30                       # 80 % inliers: log(0.01)/log(1 - 0.8^5) = 12 iterations suffice
+    # garbage: no model reaches 5 inliers -> failure, exactly solvePnPRansac's `false` (the reference then returns ret_val False)
+    junk = rng.uniform(0, 1000, (60, 2)).astype(np.float32)
+    out = orc.epnp_ransac(X[:60], junk, K, thr=0.5)
+    assert not out['ok']
+    # exactly 5 points: solved directly, all five are inliers
+    out = orc.epnp_ransac(X[:5], _project(X[:5], R, t).astype(np.float32), K, thr=1.0)
+    assert out['ok'] and out['mask'].all() and np.abs(out['tvec'] - t).max() <= 1e-2
+
+
+def test_config1_cube_with_the_reference_initialiser(orc):
+    """config 1 through the reference's whole flow: EPnP/RANSAC initialiser -> LM -> the ground-truth pose."""
+    c = syn.cube_config1()
+    x2d = c['pts2d'][None].astype(np.float32); x3d = c['pts3d'][None].astype(np.float32)
+    istd = np.ones_like(x2d)
+    ur = np.array([[-200., 1442.]], np.float32); vr = np.array([[-200., 575.]], np.float32)
+    ret, yaw, t, cov, tr, mask = orc.u2d_pnp_epnp(x2d, istd, x3d, c['K'][None].astype(np.float32), ur, vr, 0.5, 0.6,
+                                                  np.array([2.0], np.float32), True)
+    assert ret.all() and mask.all()
+    assert abs(yaw[0, 0] - c['gt_pose'][0]) <= 1e-5 and np.abs(t[0] - c['gt_pose'][1:]).max() <= 1e-4
+
+
+def k0_vs_epnp_statistics(orc, seed, B=256, num_threads=4):
+    """post-LM results of the two initialisers on one config-2 batch (shared by the test below, the GPU test and
+    tools/k0_vs_epnp.py, which prints the table kept in DESIGN.md)."""
+    b = syn.make_batch(B=B, seed=seed)
+    x2d, istd, x3d, Km, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+    r0 = orc.u2d_pnp(x2d, istd, x3d, Km, ur, vr, 0.5, 0.6, thr, True, num_threads=num_threads)
+    r1 = orc.u2d_pnp_epnp(x2d, istd, x3d, Km, ur, vr, 0.5, 0.6, thr, True, num_threads=num_threads)
+    return compare_runs(r0, r1)
+
+
+def compare_runs(r0, r1):
+    ok = r0[0] & r1[0]
+    d = np.concatenate([r0[1] - r1[1], r0[2] - r1[2]], 1).astype(np.float64)
+    d[:, 0] = np.angle(np.exp(1j * d[:, 0]))
+    same = (r0[5] == r1[5]).all(1)
+    iou = (r0[5] & r1[5]).sum(1) / np.maximum((r0[5] | r1[5]).sum(1), 1)
+    maha = np.full(len(d), np.nan)
+    for i in np.where(ok)[0]:
+        maha[i] = np.sqrt(max(d[i] @ np.linalg.solve(r1[3][i].astype(np.float64), d[i]), 0.0))
+    return dict(ok=ok, d=np.abs(d).max(1), same=same, iou=iou, maha=maha, valid0=r0[0], valid1=r1[0])
+
+
+@pytest.mark.parametrize('seed', [1234, 77])
+def test_k0_agrees_with_the_reference_initialiser_after_lm(orc, seed):
+    """R5: K0 replaces cv2 EPnP/RANSAC.  With inlier_opt_only the inlier set decides what the LM sees, so the comparison is
+    made AFTER the LM: same validity, (almost always) the same inlier set, and poses that differ by a small fraction of the
+    pose's own posterior standard deviation — by the LM's stopping tolerance when the sets are identical."""
+    s = k0_vs_epnp_statistics(orc, seed)
+    assert s['valid0'].all() and s['valid1'].all()
+    assert s['same'].mean() >= 0.80 and s['iou'].mean() >= 0.995 and s['iou'].min() >= 0.80
+    sm, df = s['same'] & s['ok'], ~s['same'] & s['ok']
+    # identical sets: the LM's stopping tolerance only — except for the rare far-away object whose yaw is hardly observable
+    # (sigma_yaw ~ 0.5 rad) and whose cost has two shallow minima a fraction of a sigma apart: allowed for < 1 % of the objects
+    assert np.nanquantile(s['maha'][sm], 0.99) <= 0.05 and np.quantile(s['d'][sm], 0.5) <= 1e-3
+    assert np.mean(s['maha'][sm] > 0.1) <= 0.01 and np.nanmax(s["maha"][sm]) <= 5.0
+    assert np.nanmax(s["maha"][df]) <= 5.0 and np.nanquantile(s['maha'][df], 0.5) <= 0.1  # different sets: well inside 1 sigma
