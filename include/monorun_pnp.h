@@ -62,6 +62,8 @@ extern "C" {
                                          torch Jacobian of jacobian.py (what `pnp_uncert`'s result_cov is) */
 #define MR_WAVES_SHIFT        8       /* bits 8..11: wavefronts cooperating on one object (0 = auto, 1,2,4,8) */
 #define MR_WAVES_MASK         (0xF << MR_WAVES_SHIFT)
+#define MR_LM_MAXIT_SHIFT      16      /* bits 16..21: Ceres' max_num_iterations for the LM (0 = the default, 50; 1..63) */
+#define MR_LM_MAXIT_MASK       (0x3F << MR_LM_MAXIT_SHIFT)
 
 /* diag[] layout (per object, 4 floats): */
 #define MR_DIAG_LM_ITERATIONS 0       /* LM loop passes executed                                  */

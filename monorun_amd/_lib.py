@@ -19,6 +19,7 @@ MR_F32, MR_F16, MR_F64, MR_BF16 = 0, 1, 2, 3
 MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
 MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES = 0x4, 0x8, 0x10
 MR_WAVES_SHIFT = 8
+MR_LM_MAXIT_SHIFT = 16
 
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
 

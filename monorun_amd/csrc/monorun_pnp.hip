@@ -216,6 +216,7 @@ struct PnpArgs {
     const double *init_pose;
     int B, P;
     double z_min; float istd_thres; int inlier_opt_only; int flags; int mean_mode;
+    int lm_max_iter;                           // Ceres max_num_iterations (50 unless MR_LM_MAXIT bits are set)
     uint8_t *valid; float *pose; float *cov; float *tr; uint8_t *mask; float *diag;
     double *pose64, *cov64, *tr64;            // legacy per-object ABI outputs (nullable)
     unsigned long long *stamps;               // debug: (B,24) s_memtime stamps (nullable)
@@ -441,6 +442,7 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
     a.tile_bytes3 = (int)(((size_t)3 * a.P * sizeof(T) + 15) & ~(size_t)15);
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
     a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
+    { const int mi = (a.flags & MR_LM_MAXIT_MASK) >> MR_LM_MAXIT_SHIFT; a.lm_max_iter = mi ? mi : 50; }
     switch (wpo) {
         case 1: return launch<T, 1>(a, st);
         case 2: return launch<T, 2>(a, st);

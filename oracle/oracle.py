@@ -82,6 +82,36 @@ def pnp_uncert(pts2d, pts3d, wgt2d, K, init_pose, clips, with_cov=False):
                 initial_cost=diag[3], final_cost=diag[4], n_success=int(diag[5]))
 
 
+TRACE_FIELDS = ('iteration', 'cost', 'candidate_cost', 'model_cost_change', 'relative_decrease', 'radius_after', 'step_norm', 'outcome')
+# outcome: 1 accepted, 0 rejected, -1 invalid step (radius halved), -2 fifth invalid step (failure), 2 / 3 parameter / function tolerance exit
+
+
+def pnp_uncert_opt(pts2d, pts3d, wgt2d, K, init_pose, clips, qr=False, max_iter=50, trace=False):
+    """`pnp_uncert` with explicit LM options: qr=True solves every trust-region step the way Ceres' DENSE_QR does (Householder QR of
+    [J S; D]) instead of through the normal equations; max_iter = Ceres' max_num_iterations; trace=True also returns the per-pass
+    record (rows of TRACE_FIELDS)."""
+    pts2d, pts3d, wgt2d, K, init_pose, clips = map(_d, (pts2d, pts3d, wgt2d, K, init_pose, clips))
+    pn = pts2d.shape[0]
+    val, pose, tr, diag = np.zeros(1, np.int32), np.zeros(4), np.zeros(1), np.zeros(6)
+    cap = 64 if trace else 0
+    tbuf = np.full((max(cap, 1), len(TRACE_FIELDS)), np.nan)
+    f = lib().orc_pnp_uncert_opt
+    f.restype = ctypes.c_int
+    n = f(_p(pts2d, c_dp), _p(pts3d, c_dp), _p(wgt2d, c_dp), _p(K, c_dp), _p(init_pose, c_dp), _p(val, c_ip), _p(pose, c_dp),
+          _p(tr, c_dp), ctypes.c_int(pn), _p(clips, c_dp), _p(diag, c_dp), ctypes.c_int(bool(qr)), ctypes.c_int(max_iter),
+          _p(tbuf, c_dp) if trace else None, ctypes.c_int(cap))
+    out = dict(val=int(val[0]), pose=pose, tr=float(tr[0]), iters=int(diag[0]), why=int(diag[1]), termination=int(diag[2]),
+               initial_cost=diag[3], final_cost=diag[4], n_success=int(diag[5]))
+    if trace:
+        out['trace'] = tbuf[:n].copy()
+    return out
+
+
+def set_lm_options(qr=False, max_iter=50):
+    """Process-wide LM options of the batch driver (u2d_pnp): step solver and max_num_iterations.  Reset with set_lm_options()."""
+    lib().orc_set_lm_options(ctypes.c_int(bool(qr)), ctypes.c_int(max_iter))
+
+
 def residual_jacobian(K, clips, pose, pts2d, pts3d, wgt2d):
     """R1: Ceres-semantics residuals (pn,2) and Jacobian (pn,2,4)."""
     pts2d, pts3d, wgt2d, K, pose, clips = map(_d, (pts2d, pts3d, wgt2d, K, pose, clips))
@@ -136,7 +166,7 @@ def istd_inlier_mask(coords_2d_istd, epnp_istd_thres):
 
 def u2d_pnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5,
             epnp_istd_thres=1.0, epnp_ransac_thres=None, inlier_opt_only=False,
-            init_pose=None, n_hyp=32, num_threads=1, return_diag=False, init_mode=0, return_init=False):
+            init_pose=None, n_hyp=32, num_threads=1, return_diag=False, init_mode=0, return_init=False, return_pose64=False):
     """R4+R5+R6 for a batch (the numpy-level driver).  Returns the reference's 6-tuple
     (ret_val, yaw, t_vec, pose_cov, tr_radius, inlier_mask) [+ diag] [+ init (B,4) fp64]; pose_cov is the
     torch-semantics inverse(J^T J) that pnp_uncert.py:71-85 computes.
@@ -162,15 +192,17 @@ def u2d_pnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_
     tr = np.zeros(B, np.float32)
     diag = np.zeros((B, 4), np.float32)
     init_out = np.zeros((B, 4))
+    pose64 = np.zeros((B, 4))
     lib().orc_u2d_pnp_batch_ex(_p(x2d, c_fp), _p(istd, c_fp), _p(x3d, c_fp), _p(K, c_fp), ctypes.c_int(K.shape[0]),
                                _p(ur, c_fp), _p(vr, c_fp), ctypes.c_int(ur.shape[0]), _p(thr, c_fp), _p(ini, c_dp),
                                ctypes.c_int(B), ctypes.c_int(P), ctypes.c_double(z_min), ctypes.c_int(bool(inlier_opt_only)),
                                ctypes.c_int(n_hyp), ctypes.c_int(init_mode), ctypes.c_int(num_threads), _p(mask, c_u8p), _p(valid, c_u8p),
-                               _p(pose, c_fp), _p(cov, c_fp), _p(tr, c_fp), _p(diag, c_fp), _p(init_out, c_dp))
+                               _p(pose, c_fp), _p(cov, c_fp), _p(tr, c_fp), _p(diag, c_fp), _p(init_out, c_dp), _p(pose64, c_dp))
     out = (valid.astype(bool), pose[:, :1].copy(), pose[:, 1:].copy(), cov.reshape(B, 4, 4),
            tr[:, None].copy(), mask.astype(bool))
     out = out + (diag,) if return_diag else out
-    return out + (init_out,) if return_init else out
+    out = out + (init_out,) if return_init else out
+    return out + (pose64,) if return_pose64 else out
 
 
 def u2d_pnp_epnp(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,

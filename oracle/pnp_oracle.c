@@ -179,9 +179,58 @@ typedef struct {
 } orc_lm_summary;
 
 typedef int (*orc_eval_fn)(const void *ctx, const double *x, double *cost, double *g, double *H);
+/* residuals r[nres] and Jacobian J[nres][n] (row-major) at x — needed only by the DENSE_QR step solver */
+typedef void (*orc_jac_fn)(const void *ctx, const double *x, double *r, double *J);
 #define ORC_MAXN 7
-static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init, double *out, orc_lm_summary *sm) {
-    const int    max_num_iterations = 50;
+
+/* Options of one LM run.  qr = 0: the trust-region step through the Jacobi-scaled normal equations (Cholesky) — what the
+ * HIP kernel does;  qr = 1: literally what Ceres' DENSE_QR does (dense_qr_solver.cc: Householder QR of the augmented
+ * (m+n) x n matrix [J S; D], right-hand side [r; 0]) and the model cost change from the model residuals J S step
+ * (trust_region_minimizer.cc).  max_iter: Ceres' max_num_iterations (default 50).  trace: optional per-pass record. */
+#define ORC_TRACE_W 8   /* iteration, cost, candidate cost, model cost change, relative decrease, radius after, step norm, outcome */
+typedef struct { int qr, max_iter; double *trace; int trace_cap, trace_n; } orc_lm_opts;
+static orc_lm_opts orc_default_opts = { 0, 50, NULL, 0, 0 };
+void orc_set_lm_options(int qr, int max_iter) { orc_default_opts.qr = qr; orc_default_opts.max_iter = max_iter > 0 ? max_iter : 50; }
+
+/* least squares min ||A y - b|| by Householder reflections (no pivoting), A is m x n row-major (destroyed), b[m] (destroyed) */
+static int orc_householder_ls(int m, int n, double *A, double *b, double *y) {
+    for (int k = 0; k < n; ++k) {
+        double nrm = 0.0;
+        for (int i = k; i < m; ++i) nrm += A[n * i + k] * A[n * i + k];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0) || !isfinite(nrm)) return 0;
+        const double alpha = A[n * k + k] > 0.0 ? -nrm : nrm;
+        const double v0 = A[n * k + k] - alpha;
+        /* v = (v0, A[k+1.., k]); H = I - 2 v v^T / (v^T v) */
+        double vtv = v0 * v0;
+        for (int i = k + 1; i < m; ++i) vtv += A[n * i + k] * A[n * i + k];
+        if (vtv > 0.0) {
+            for (int j = k + 1; j < n; ++j) {
+                double d = v0 * A[n * k + j];
+                for (int i = k + 1; i < m; ++i) d += A[n * i + k] * A[n * i + j];
+                const double f = 2.0 * d / vtv;
+                A[n * k + j] -= f * v0;
+                for (int i = k + 1; i < m; ++i) A[n * i + j] -= f * A[n * i + k];
+            }
+            double d = v0 * b[k];
+            for (int i = k + 1; i < m; ++i) d += A[n * i + k] * b[i];
+            const double f = 2.0 * d / vtv;
+            b[k] -= f * v0;
+            for (int i = k + 1; i < m; ++i) b[i] -= f * A[n * i + k];
+        }
+        A[n * k + k] = alpha;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int j = i + 1; j < n; ++j) s -= A[n * i + j] * y[j];
+        y[i] = s / A[n * i + i];
+    }
+    return 1;
+}
+
+static void orc_lm_n_ex(int n, orc_eval_fn ev, orc_jac_fn jf, int nres, const void *ctx, const double *init, double *out,
+                        orc_lm_summary *sm, orc_lm_opts *op) {
+    const int    max_num_iterations = op->max_iter;
     const double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
     const double min_relative_decrease = 1e-3;
     const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
@@ -214,6 +263,7 @@ static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init,
         if (radius <= min_radius) { sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_MINRADIUS; return; }
 
         ++iteration; last_successful = 0;
+        const double trace_cost = cost;
         /* ComputeTrustRegionStep — LevenbergMarquardtStrategy::ComputeStep on the scaled Jacobian */
         double Hs[ORC_MAXN * ORC_MAXN], gs[ORC_MAXN], A[ORC_MAXN * ORC_MAXN], D2[ORC_MAXN], y[ORC_MAXN], step[ORC_MAXN];
         for (int a = 0; a < n; ++a) { gs[a] = g[a] * scale[a]; for (int b = 0; b < n; ++b) Hs[n * a + b] = H[n * a + b] * scale[a] * scale[b]; }
@@ -221,20 +271,45 @@ static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init,
             double d = Hs[(n + 1) * j]; d = fmin(fmax(d, min_lm_diagonal), max_lm_diagonal);
             D2[j] = d / radius;                       /* lm_diagonal = sqrt(diagonal/radius); D^2 enters the normal eqs */
         }
-        memcpy(A, Hs, sizeof(double) * n * n); for (int j = 0; j < n; ++j) A[(n + 1) * j] += D2[j];
-        int step_ok = orc_chol_solve(n, A, gs, y);
-        if (step_ok) for (int j = 0; j < n; ++j) { step[j] = -y[j]; if (!isfinite(step[j])) step_ok = 0; }
+        int step_ok;
         double model_cost_change = 0.0;
-        if (step_ok) {
-            /* model_cost_change = -(J s)^T (r + J s / 2) = -(s^T gs + 1/2 s^T Hs s) */
-            double sg = 0.0, sHs = 0.0;
-            for (int a = 0; a < n; ++a) { sg += step[a] * gs[a]; double t = 0.0; for (int b = 0; b < n; ++b) t += Hs[n * a + b] * step[b]; sHs += step[a] * t; }
-            model_cost_change = -(sg + 0.5 * sHs);
-            step_ok = (model_cost_change > 0.0);
+        double *qr_buf = NULL;
+        if (op->qr && jf) {
+            /* DENSE_QR: [J S; D] y = [r; 0] in the least-squares sense, step = -y */
+            const int m = nres + n;
+            qr_buf = (double *)malloc(sizeof(double) * ((size_t)nres * n + (size_t)nres + (size_t)m * n + (size_t)m));
+            double *Jm = qr_buf, *rv = Jm + (size_t)nres * n, *Aq = rv + nres, *bq = Aq + (size_t)m * n;
+            jf(ctx, x, rv, Jm);
+            for (int i = 0; i < nres; ++i) { for (int j = 0; j < n; ++j) { Jm[(size_t)n * i + j] *= scale[j]; Aq[(size_t)n * i + j] = Jm[(size_t)n * i + j]; } bq[i] = rv[i]; }
+            for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) Aq[(size_t)n * (nres + i) + j] = (i == j) ? sqrt(D2[j]) : 0.0; bq[nres + i] = 0.0; }
+            step_ok = orc_householder_ls(m, n, Aq, bq, y);
+            if (step_ok) for (int j = 0; j < n; ++j) { step[j] = -y[j]; if (!isfinite(step[j])) step_ok = 0; }
+            if (step_ok) {
+                /* model_residuals = (J S) step ; model_cost_change = -model_residuals . (residuals + model_residuals / 2) */
+                double acc = 0.0;
+                for (int i = 0; i < nres; ++i) { double mr = 0.0; for (int j = 0; j < n; ++j) mr += Jm[(size_t)n * i + j] * step[j]; acc += mr * (rv[i] + 0.5 * mr); }
+                model_cost_change = -acc;
+                step_ok = (model_cost_change > 0.0);
+            }
+        } else {
+            memcpy(A, Hs, sizeof(double) * n * n); for (int j = 0; j < n; ++j) A[(n + 1) * j] += D2[j];
+            step_ok = orc_chol_solve(n, A, gs, y);
+            if (step_ok) for (int j = 0; j < n; ++j) { step[j] = -y[j]; if (!isfinite(step[j])) step_ok = 0; }
+            if (step_ok) {
+                /* model_cost_change = -(J s)^T (r + J s / 2) = -(s^T gs + 1/2 s^T Hs s) */
+                double sg = 0.0, sHs = 0.0;
+                for (int a = 0; a < n; ++a) { sg += step[a] * gs[a]; double t = 0.0; for (int b = 0; b < n; ++b) t += Hs[n * a + b] * step[b]; sHs += step[a] * t; }
+                model_cost_change = -(sg + 0.5 * sHs);
+                step_ok = (model_cost_change > 0.0);
+            }
         }
+        free(qr_buf);
+#define ORC_TRACE(cc, rd, sn, oc) do { if (op->trace && op->trace_n < op->trace_cap) { double *tr_ = op->trace + (size_t)ORC_TRACE_W * op->trace_n++; \
+            tr_[0] = iteration; tr_[1] = trace_cost; tr_[2] = (cc); tr_[3] = model_cost_change; tr_[4] = (rd); tr_[5] = radius; tr_[6] = (sn); tr_[7] = (oc); } } while (0)
         if (!step_ok) {                                  /* HandleInvalidStep */
-            if (++invalid_run >= max_consecutive_invalid) { sm->termination = ORC_FAILURE; sm->why = ORC_WHY_INVALID; sm->num_iterations = iteration; return; }
+            if (++invalid_run >= max_consecutive_invalid) { ORC_TRACE(NAN, NAN, NAN, -2.0); sm->termination = ORC_FAILURE; sm->why = ORC_WHY_INVALID; sm->num_iterations = iteration; return; }
             radius *= 0.5;                               /* StepIsInvalid */
+            ORC_TRACE(NAN, NAN, NAN, -1.0);
             continue;
         }
         invalid_run = 0;
@@ -245,10 +320,12 @@ static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init,
         /* ParameterToleranceReached — uses ||x - candidate|| */
         double step_norm = 0.0; for (int j = 0; j < n; ++j) { double d = x[j] - cand[j]; step_norm += d * d; } step_norm = sqrt(step_norm);
         if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) {
+            ORC_TRACE(cand_cost, NAN, step_norm, 2.0);
             sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_PARAMETER; sm->num_iterations = iteration; return; }
         /* FunctionToleranceReached */
         double cost_change = cost - cand_cost;
         if (fabs(cost_change) <= function_tolerance * cost) {
+            ORC_TRACE(cand_cost, NAN, step_norm, 3.0);
             sm->termination = ORC_CONVERGENCE; sm->why = ORC_WHY_FUNCTION; sm->num_iterations = iteration; return; }
         double relative_decrease = cost_change / model_cost_change;        /* monotonic StepQuality */
         if (relative_decrease > min_relative_decrease) {                   /* HandleSuccessfulStep */
@@ -259,17 +336,33 @@ static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init,
             radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
             radius = fmin(max_radius, radius);
             decrease_factor = 2.0;
+            ORC_TRACE(cand_cost, relative_decrease, step_norm, 1.0);
         } else {                                                           /* HandleUnsuccessfulStep / StepRejected */
             radius = radius / decrease_factor; decrease_factor *= 2.0;
+            ORC_TRACE(cand_cost, relative_decrease, step_norm, 0.0);
         }
     }
 }
 
+static void orc_lm_n(int n, orc_eval_fn ev, const void *ctx, const double *init, double *out, orc_lm_summary *sm) {
+    orc_lm_opts op = orc_default_opts; op.qr = 0; op.trace = NULL;      /* the 7-parameter variants: normal equations only */
+    orc_lm_n_ex(n, ev, NULL, 0, ctx, init, out, sm, &op);
+}
 static int orc_eval4_cb(const void *ctx, const double *x, double *cost, double *g, double *H) {
     return orc_eval((const orc_problem *)ctx, x, cost, g, H);
 }
+static void orc_jac4_cb(const void *ctx, const double *x, double *r, double *J) {
+    const orc_problem *pb = (const orc_problem *)ctx;
+    for (int i = 0; i < pb->pn; ++i)
+        orc_residual_jet(&pb->cam, x, pb->pts2d[2 * i], pb->pts2d[2 * i + 1], pb->pts3d[3 * i], pb->pts3d[3 * i + 1],
+                         pb->pts3d[3 * i + 2], pb->wgt2d[2 * i], pb->wgt2d[2 * i + 1], r + 2 * i, J + 8 * i);
+}
+static void orc_lm_opt(const orc_problem *pb, const double init[4], double out[4], orc_lm_summary *sm, orc_lm_opts *op) {
+    orc_lm_n_ex(4, orc_eval4_cb, orc_jac4_cb, 2 * pb->pn, pb, init, out, sm, op);
+}
 static void orc_lm(const orc_problem *pb, const double init[4], double out[4], orc_lm_summary *sm) {
-    orc_lm_n(4, orc_eval4_cb, pb, init, out, sm);
+    orc_lm_opts op = orc_default_opts; op.trace = NULL;
+    orc_lm_opt(pb, init, out, sm, &op);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -295,6 +388,23 @@ void orc_pnp_uncert_diag(double *pts2d, double *pts3d, double *wgt2d, double *K,
         *result_val = ok ? 1 : 0;
         if (ok) memcpy(result_cov, inv, sizeof inv);
     }
+}
+
+/* the same solve with explicit options and an optional per-pass trace (trace_cap rows of ORC_TRACE_W doubles) */
+int orc_pnp_uncert_opt(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose,
+                       int *result_val, double *result_pose, double *result_tr, int pn, double *clips, double *diag,
+                       int qr, int max_iter, double *trace, int trace_cap) {
+    orc_problem pb;
+    pb.cam.fx = K[0]; pb.cam.fy = K[4]; pb.cam.cx = K[2]; pb.cam.cy = K[5];
+    pb.cam.z_min = clips[0]; pb.cam.u_min = clips[1]; pb.cam.u_max = clips[2]; pb.cam.v_min = clips[3]; pb.cam.v_max = clips[4];
+    pb.pn = pn; pb.pts2d = pts2d; pb.pts3d = pts3d; pb.wgt2d = wgt2d;
+    orc_lm_summary sm;
+    orc_lm_opts op = { qr, max_iter > 0 ? max_iter : 50, trace, trace_cap, 0 };
+    orc_lm_opt(&pb, init_pose, result_pose, &sm, &op);
+    *result_val = (sm.termination == ORC_CONVERGENCE || sm.termination == ORC_NO_CONVERGENCE) ? 1 : 0;
+    *result_tr = sm.radius;
+    if (diag) { diag[0] = sm.num_iterations; diag[1] = sm.why; diag[2] = sm.termination; diag[3] = sm.initial_cost; diag[4] = sm.final_cost; diag[5] = sm.num_successful; }
+    return op.trace_n;
 }
 
 void orc_pnp_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose,
@@ -668,7 +778,8 @@ static int orc_epnp_init(const float *x2d, const float *x3d, uint8_t *mask, int 
 static void orc_one_object(const float *x2d, const float *istd, const float *x3d, const float *K,
                            const float *ur, const float *vr, const float *thr, const double *init,
                            int pn, double z_min, int inlier_opt_only, int n_hyp, int init_mode /* 0 = K0, 1 = EPnP/RANSAC restatement */,
-                           uint8_t *mask, uint8_t *valid, float *pose, float *cov, float *tr, float *diag, double *init_out /* nullable 4 */) {
+                           uint8_t *mask, uint8_t *valid, float *pose, float *cov, float *tr, float *diag, double *init_out /* nullable 4 */,
+                           double *pose64 /* nullable 4: the LM's fp64 iterate */) {
     int cnt = 0; for (int p = 0; p < pn; ++p) cnt += mask[p] ? 1 : 0;
     if (!(cnt > 4)) { for (int p = 0; p < pn; ++p) mask[p] = 1; }                       /* pnp_uncert_cpu.py:23-32 */
     double init_pose[4] = {0, 0, 0, 0}; int ok, bh = -1, bc = 0;
@@ -692,6 +803,7 @@ static void orc_one_object(const float *x2d, const float *istd, const float *x3d
     }
     /* float32 outputs (pnp_uncert_cpu.py:108-125) */
     for (int j = 0; j < 4; ++j) pose[j] = ok ? (float)res_pose[j] : 0.0f;
+    if (pose64) for (int j = 0; j < 4; ++j) pose64[j] = ok ? res_pose[j] : 0.0;
     *tr = ok ? (float)res_tr : 0.0f;
     *valid = (uint8_t)(ok && res_val);
     if (diag) { diag[0] = (float)dg[0]; diag[1] = (float)dg[4]; diag[2] = ok ? (float)dg[1] : 8.0f /* initialiser failed */; diag[3] = (float)bc; }
@@ -714,7 +826,8 @@ void orc_u2d_pnp_batch_ex(const float *x2d, const float *istd, const float *x3d,
                           const float *ransac_thr /*nullable (B)*/, const double *init_pose /*nullable (B,4)*/,
                           int B, int P, double z_min, int inlier_opt_only, int n_hyp, int init_mode, int num_threads,
                           uint8_t *mask /*B,P in/out*/, uint8_t *valid /*B*/, float *pose /*B,4*/,
-                          float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/, double *init_out /*nullable B,4*/) {
+                          float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/, double *init_out /*nullable B,4*/,
+                          double *pose64 /*nullable B,4*/) {
 #ifdef _OPENMP
     if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel for schedule(dynamic, 4) if (num_threads != 1)
@@ -725,7 +838,7 @@ void orc_u2d_pnp_batch_ex(const float *x2d, const float *istd, const float *x3d,
                        ransac_thr ? ransac_thr + b : NULL, init_pose ? init_pose + (size_t)b * 4 : NULL,
                        P, z_min, inlier_opt_only, n_hyp, init_mode,
                        mask + (size_t)b * P, valid + b, pose + (size_t)b * 4, cov + (size_t)b * 16, tr + b, diag ? diag + (size_t)b * 4 : NULL,
-                       init_out ? init_out + (size_t)b * 4 : NULL);
+                       init_out ? init_out + (size_t)b * 4 : NULL, pose64 ? pose64 + (size_t)b * 4 : NULL);
     }
 }
 
@@ -736,7 +849,7 @@ void orc_u2d_pnp_batch(const float *x2d, const float *istd, const float *x3d,
                        uint8_t *mask /*B,P in/out*/, uint8_t *valid /*B*/, float *pose /*B,4*/,
                        float *cov /*B,16*/, float *tr /*B*/, float *diag /*nullable B,4*/) {
     orc_u2d_pnp_batch_ex(x2d, istd, x3d, K, Kb, u_range, v_range, Rb, ransac_thr, init_pose, B, P, z_min, inlier_opt_only, n_hyp, 0,
-                         num_threads, mask, valid, pose, cov, tr, diag, NULL);
+                         num_threads, mask, valid, pose, cov, tr, diag, NULL, NULL);
 }
 
 int orc_max_threads(void) {

@@ -1,0 +1,120 @@
+"""G7 (tests/golden/g7_lm_trajectories.npz): committed LM trajectories of 64 objects — ordinary convergence by every tolerance,
+rejected steps, max-iteration exits, an evaluation failure, z/u/v clamps, degenerate inputs.
+  * CPU: the oracle reproduces the committed data in BOTH step-solver modes (Cholesky of the normal equations = what the
+    HIP kernel does; Householder QR of [J S; D] = what Ceres' DENSE_QR does, pnp_uncert_cpu.cpp:270-274), and the two modes
+    agree on a config-2 batch to 1e-10 in the fp64 pose with identical iteration counts / exit reasons.
+  * GPU: the kernel, run with max_num_iterations = k for every k, matches the committed trajectory pass by pass (cost and
+    trust-region radius after pass k, iteration count, exit reason) and the committed final pose."""
+import os
+
+import numpy as np
+import pytest
+
+from monorun_amd import synthetic as syn
+
+G7 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g7_lm_trajectories.npz')
+IT, COST, CAND, MCC, RD, RAD, SN, OUT = range(8)
+
+
+@pytest.fixture(scope='module')
+def g7():
+    return dict(np.load(G7, allow_pickle=True))
+
+
+def _solve(orc, z, i, **kw):
+    clips = np.array([0.5, z['ur'][i, 0], z['ur'][i, 1], z['vr'][i, 0], z['vr'][i, 1]], np.float64)
+    return orc.pnp_uncert_opt(z['x2d'][i].astype(np.float64), z['x3d'][i].astype(np.float64), z['w'][i].astype(np.float64),
+                              z['K'][i].astype(np.float64), z['init'][i], clips, **kw)
+
+
+def test_fixture_covers_the_control_flow(g7):
+    z = g7
+    assert z['x2d'].shape == (64, 196, 2) and set(np.unique(z['why'])) >= {1, 2, 3, 4, 7}
+    out = z['trace'][:, :, OUT]
+    assert (out == 0).any(1).sum() >= 10, 'rejected steps'
+    assert (z['iters'] == 50).sum() >= 3 and (z['iters'] == 0).sum() >= 2
+    # 73 of the 1924 candidates were left out: there the normal equations and QR part ways (iteration count, exit reason, or a final
+    # pose that differs by more than 1e-7) because J S is numerically rank-deficient — 71 with the initial pose at / behind the camera
+    # (every point z-clamped: directions without information), 2 started more than 10 m off
+    assert int(z['pool_size']) == 1924 and z['pool_divergent_qr_vs_cholesky'].tolist() == [['far', '2'], ['zclamp', '71']]
+
+
+@pytest.mark.parametrize('qr', [False, True])
+def test_oracle_reproduces_the_committed_trajectories(orc, g7, qr):
+    z = g7
+    for i in range(64):
+        r = _solve(orc, z, i, qr=qr, trace=True)
+        assert (r['iters'], r['why'], r['val']) == (z['iters'][i], z['why'][i], z['val'][i]), (i, z['tag'][i])
+        n = int(z['n_pass'][i])
+        assert len(r['trace']) == n
+        a, b = r['trace'], z['trace'][i, :n]
+        assert np.array_equal(a[:, OUT], b[:, OUT]) and np.array_equal(np.isnan(a), np.isnan(b))
+        # the committed data came from the QR mode; the Cholesky mode agrees to the conditioning of the normal equations
+        for col, tol in ((COST, 1e-12), (CAND, 1e-9), (RAD, 1e-9 if qr else 1e-5), (RD, 1e-9 if qr else 1e-4)):
+            ok = ~np.isnan(b[:, col])
+            atol = 1e-12 * np.nanmax(b[:, COST]) if (col in (COST, CAND) and n) else 1e-300     # costs that reached rounding level are noise
+            assert np.allclose(a[ok, col], b[ok, col], rtol=tol if qr else max(tol, 1e-6), atol=atol), (i, z['tag'][i], col)
+        if z['val'][i]:
+            assert np.abs(r['pose'] - z['pose'][i]).max() <= (1e-9 if qr else 1e-6) * max(1.0, np.abs(z['pose'][i]).max()), (i, z['tag'][i])
+
+
+def test_qr_and_cholesky_step_solvers_agree_on_config2(orc):
+    """the normal equations are a faithful stand-in for DENSE_QR on the workload: identical iteration counts, exit reasons,
+    masks; fp64 poses within 1e-10 (204 800-object version: tools/lm_qr_vs_chol_sweep.py, result in DESIGN.md §4)."""
+    for seed in (1234, 5):
+        b = syn.make_batch(B=256, seed=seed)
+        x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+        try:
+            orc.set_lm_options(qr=False)
+            r0 = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_pose64=True, num_threads=0)
+            orc.set_lm_options(qr=True)
+            r1 = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_pose64=True, num_threads=0)
+        finally:
+            orc.set_lm_options()
+        assert np.array_equal(r0[6][:, 0], r1[6][:, 0]) and np.array_equal(r0[6][:, 2], r1[6][:, 2]) and np.array_equal(r0[5], r1[5])
+        assert np.abs(r0[7] - r1[7]).max() <= 1e-10 and np.array_equal(r0[4], r1[4])
+
+
+@pytest.mark.gpu
+def test_kernel_follows_the_committed_trajectories_pass_by_pass(g7):
+    import torch
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    z = g7
+    dev = torch.device('cuda:0')
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    x2d, w, x3d, K, ur, vr = t(z['x2d']), t(z['w']), t(z['x3d']), t(z['K']), t(z['ur']), t(z['vr'])
+    init = t(z['init'], torch.float64)
+    tr_ = z['trace']
+
+    def run(max_iter):
+        flags = _lib.MR_NO_ISTD_MASK | (max_iter << _lib.MR_LM_MAXIT_SHIFT)
+        valid, pose, cov, tr, mask, diag = pnp_uncert_device(x2d, w, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=None,
+                                                             inlier_opt_only=False, init_pose=init, flags=flags, with_diag=True)
+        torch.cuda.synchronize()
+        return valid.cpu().numpy().astype(bool), pose.cpu().numpy(), tr.cpu().numpy(), diag.cpu().numpy()
+    # the full run: iteration counts, exit reasons, validity, final pose, final radius
+    valid, pose, tr, diag = run(0)
+    fail = z['why'] == 7
+    assert np.array_equal(diag[:, 0].astype(int), z['iters']) and np.array_equal(diag[:, 2].astype(int), z['why'])
+    assert np.array_equal(valid[~fail], z['val'][~fail].astype(bool))
+    ok = z['val'].astype(bool)
+    assert np.abs(pose[ok] - z['pose'][ok].astype(np.float32)).max() <= 1e-4
+    assert np.allclose(tr[ok], z['radius'][ok].astype(np.float32), rtol=1e-5)
+    # truncated runs: after k passes the kernel holds the committed cost and radius of pass k (invalid-step passes, if any, would
+    # not count as iterations in Ceres either: the fixture has none)
+    for k in range(1, int(z['iters'].max()) + 1):
+        valid, pose, tr, diag = run(k) if k < 50 else (valid, pose, tr, diag)
+        live = z['iters'] >= k                                    # objects that execute a k-th pass
+        if not live.any():
+            continue
+        idx = np.where(live)[0]
+        row = tr_[idx, k - 1]
+        stopped_here = (z['iters'][idx] == k) & np.isin(row[:, OUT], (2, 3))          # tolerance exit inside pass k: candidate discarded
+        exp_cost = np.where(row[:, OUT] == 1, row[:, CAND], row[:, COST])
+        assert np.array_equal(diag[idx, 0].astype(int), np.full(len(idx), k)), k
+        exp_why = np.where(stopped_here, z['why'][idx], 4)
+        exp_why = np.where((z['iters'][idx] == k) & ~stopped_here, z['why'][idx], exp_why)      # e.g. the 50th pass of a max-iteration object
+        assert np.array_equal(diag[idx, 2].astype(int), exp_why), k
+        assert np.allclose(diag[idx, 1], exp_cost.astype(np.float32), rtol=2e-6), k
+        assert np.allclose(tr[idx], row[:, RAD].astype(np.float32), rtol=1e-5), k
