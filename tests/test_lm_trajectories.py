@@ -88,7 +88,7 @@ def test_kernel_follows_the_committed_trajectories_pass_by_pass(g7):
     tr_ = z['trace']
 
     def run(max_iter):
-        flags = _lib.MR_NO_ISTD_MASK | (max_iter << _lib.MR_LM_MAXIT_SHIFT)
+        flags = _lib.MR_NO_ISTD_MASK | _lib.MR_COV_NONE | (max_iter << _lib.MR_LM_MAXIT_SHIFT)     # no covariance: `valid` is the LM's own verdict
         valid, pose, cov, tr, mask, diag = pnp_uncert_device(x2d, w, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=None,
                                                              inlier_opt_only=False, init_pose=init, flags=flags, with_diag=True)
         torch.cuda.synchronize()
