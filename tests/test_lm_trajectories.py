@@ -94,7 +94,8 @@ def test_kernel_follows_the_committed_trajectories_pass_by_pass(g7):
         torch.cuda.synchronize()
         return valid.cpu().numpy().astype(bool), pose.cpu().numpy(), tr.cpu().numpy(), diag.cpu().numpy()
     # the full run: iteration counts, exit reasons, validity, final pose, final radius
-    valid, pose, tr, diag = run(0)
+    full = run(0)
+    valid, pose, tr, diag = full
     fail = z['why'] == 7
     assert np.array_equal(diag[:, 0].astype(int), z['iters']) and np.array_equal(diag[:, 2].astype(int), z['why'])
     assert np.array_equal(valid[~fail], z['val'][~fail].astype(bool))
@@ -104,7 +105,7 @@ def test_kernel_follows_the_committed_trajectories_pass_by_pass(g7):
     # truncated runs: after k passes the kernel holds the committed cost and radius of pass k (invalid-step passes, if any, would
     # not count as iterations in Ceres either: the fixture has none)
     for k in range(1, int(z['iters'].max()) + 1):
-        valid, pose, tr, diag = run(k) if k < 50 else (valid, pose, tr, diag)
+        valid, pose, tr, diag = run(k) if k < 50 else full
         live = z['iters'] >= k                                    # objects that execute a k-th pass
         if not live.any():
             continue
