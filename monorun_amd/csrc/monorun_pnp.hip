@@ -99,6 +99,52 @@ __global__ void __launch_bounds__(256) roi_align_avg_kernel(const float *in, con
                                  r[4] * spatial_scale, ph, pw, out_h, out_w, sampling_ratio, aligned);
 }
 
+// exp / log of the istd chain, SPECIFIED (not library calls): the decoded istd feeds a bit-exact threshold (the istd inlier
+// mask, pnp_uncert_cpu.py:164-168), so its last bit must not depend on which libm / device library computed it.  Classical
+// single-precision algorithms (Cephes expf / logf: Cody-Waite reduction with the two-part ln 2, degree-5 / degree-8
+// polynomials) written as a fixed sequence of IEEE float32 multiplications and additions — no fma, no contraction — which the
+// oracle restates operation for operation with numpy float32 arithmetic (oracle.spec_expf / spec_logf).  Error <= 1 ulp.
+__device__ __forceinline__ float mr_expf(float x) {
+#pragma clang fp contract(off)
+    if (x > 88.72283935546875f) return __int_as_float(0x7f800000);
+    if (x < -103.0f) return 0.0f;
+    const float kf = rintf(x * 1.44269504088896341f);
+    float r = x - kf * 0.693359375f;
+    r = r - kf * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500E-4f * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    float y = p * z + r;
+    y = y + 1.0f;
+    return ldexpf(y, (int)kf);                 // NaN in -> NaN out (both range tests are false)
+}
+__device__ __forceinline__ float mr_logf(float x) {
+#pragma clang fp contract(off)
+    if (!(x > 0.0f)) return x == 0.0f ? -__int_as_float(0x7f800000) : __int_as_float(0x7fc00000);
+    if (x == __int_as_float(0x7f800000)) return x;
+    int e;
+    float m = frexpf(x, &e);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else m = m - 1.0f;
+    const float z = m * m;
+    float p = 7.0376836292E-2f * m - 1.1514610310E-1f;
+    p = p * m + 1.1676998740E-1f;
+    p = p * m - 1.2420140846E-1f;
+    p = p * m + 1.4249322787E-1f;
+    p = p * m - 1.6668057665E-1f;
+    p = p * m + 2.0000714765E-1f;
+    p = p * m - 2.4999993993E-1f;
+    p = p * m + 3.3333331174E-1f;
+    const float fe = (float)e;
+    float y = m * (z * p);
+    y = y + -2.12194440e-4f * fe;
+    y = y - 0.5f * z;
+    const float zz = m + y;
+    return zz + 0.693359375f * fe;
+}
+
 struct DecodeObj { float dm[3], dv[3], nm[3], ns[3]; float x1, y1, x2, y2, su, sv, thr; long long base; int ch_noc, ch_ls; };   // base: element offset of the object
 
 __device__ __forceinline__ float pred_at(const DecodeArgs &a, long long i) {
@@ -155,9 +201,9 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
     for (int k = 0; k < 2; ++k) {
         const float ls = pred_at(a, o.base + (long long)(o.ch_ls + k) * hw + p);
         float lspx;
-        if (a.has_var) lspx = 0.5f * logf((v2[k] * a.k_epi + expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
+        if (a.has_var) lspx = 0.5f * mr_logf((v2[k] * a.k_epi + mr_expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
         else lspx = ls + 0.0f;                                    // log(sd / sd)
-        istd[k] = expf(-lspx) / a.std_scale;
+        istd[k] = mr_expf(-lspx) / a.std_scale;
     }
     if (a.map2d) {      // roi_align(coord_2d, rois, (h, w), 1.0, 0, 'avg', True)   (monorun_roi_head.py:521-523)
         c2d[0] = roi_align_avg_bin(a.map2d, a.map_h, a.map_w, o.x1, o.y1, o.x2, o.y2, py, px, a.h, a.w, 0, 1);
@@ -206,9 +252,8 @@ struct PairwisePlan {
 struct PnpArgs {
     const void *x2d, *istd, *x3d;
     long long s2[3], sw[3], s3[3];            // global element strides (b, p, c)
-    int contig2, contigw, contig3;             // per-object block is contiguous -> verbatim LDS-DMA copy
-    int lps2, lcs2, lpsw, lcsw, lps3, lcs3;    // LDS tile strides (point, channel) in elements
-    int tile_bytes2, tile_bytes3;              // LDS bytes of a 2-channel / 3-channel block (16-byte multiples)
+    int vec;                                   // 1: point stride 1 on all three tensors (channel-planar rows): load_records' coalesced path
+    int elem_size;                             // sizeof(T) of the correspondence tensors
     int nca, nla;                              // LDS carve: chunk slots (multiple of 4), pairwise leaves (>= 1)
     const void *K; int K_stride; int K_f64;    // K_stride 0 (broadcast) or 9
     const void *ur, *vr; int r_stride; int r_f64;
@@ -356,7 +401,7 @@ size_t lds_bytes(const PnpArgs &a, int wpo) {
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
     n += sizeof(float) * (4 * a.nla + 4);
-    n += (size_t)2 * a.tile_bytes2 + a.tile_bytes3;
+    n += (size_t)8 * a.P * a.elem_size;                    // point records
     n += 2 * sizeof(uint16_t) * ((a.P + 7) & ~7);        // candidate list + final inlier list
     n += a.P;
     return (n + 15) & ~(size_t)15;
@@ -406,13 +451,6 @@ std::atomic<int> g_last_hip_error{0};
 unsigned long long *g_stamps = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
-// per-object block layout: contiguous (interleaved or planar) blocks keep their HBM layout in LDS
-void block_layout(const long long s[3], int C, int P, int &contig, int &lps, int &lcs) {
-    if (s[2] == 1 && s[1] == C) { contig = 1; lps = C; lcs = 1; }            // (P, C) interleaved
-    else if (s[1] == 1 && s[2] == P) { contig = 1; lps = 1; lcs = P; }       // (C, P) channel-planar
-    else { contig = 0; lps = 1; lcs = P; }                                    // gathered into a planar image
-}
-
 template <typename T, int WPO>
 int launch(const PnpArgs &a, hipStream_t st) {
     const size_t lds = lds_bytes(a, WPO);
@@ -435,11 +473,8 @@ int launch(const PnpArgs &a, hipStream_t st) {
 
 template <typename T>
 int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
-    block_layout(a.s2, 2, a.P, a.contig2, a.lps2, a.lcs2);
-    block_layout(a.sw, 2, a.P, a.contigw, a.lpsw, a.lcsw);
-    block_layout(a.s3, 3, a.P, a.contig3, a.lps3, a.lcs3);
-    a.tile_bytes2 = (int)(((size_t)2 * a.P * sizeof(T) + 15) & ~(size_t)15);
-    a.tile_bytes3 = (int)(((size_t)3 * a.P * sizeof(T) + 15) & ~(size_t)15);
+    a.elem_size = (int)sizeof(T);
+    a.vec = (!a.from_head && a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;      // channel-planar rows: coalesced per-point loads
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
     a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
     { const int mi = (a.flags & MR_LM_MAXIT_MASK) >> MR_LM_MAXIT_SHIFT; a.lm_max_iter = mi ? mi : 50; }

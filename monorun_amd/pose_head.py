@@ -338,13 +338,14 @@ class UncertPropPnPOptimizer(nn.Module):
                                                     cam_intrinsic, u_range, v_range, thr)
         return ret_val, yaw, t_vec, pose_cov, self._calibrate(pose_cov)
 
-    def forward_decoded(self, dec, cam_intrinsic, img_shapes):
+    def forward_decoded(self, dec, cam_intrinsic, img_shapes, with_mask=False):
         """Same as ``forward`` but fed by ``noc_decode`` (istd and RANSAC threshold already on the device)."""
         u_range, v_range = self._ranges(dec['coords_2d'], img_shapes)
-        ret_val, yaw, t_vec, pose_cov, _ = self.pnp(_planar_view(dec['coords_2d']), _planar_view(dec['coords_2d_istd']),
+        ret_val, yaw, t_vec, pose_cov, mask = self.pnp(_planar_view(dec['coords_2d']), _planar_view(dec['coords_2d_istd']),
                                                     _planar_view(dec['coords_3d']), cam_intrinsic, u_range, v_range,
                                                     dec['ransac_thr'])
-        return ret_val, yaw, t_vec, pose_cov, self._calibrate(pose_cov)
+        out = (ret_val, yaw, t_vec, pose_cov, self._calibrate(pose_cov))
+        return out + (mask,) if with_mask else out
 
 
 def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape,
@@ -355,21 +356,21 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
     if fused:
         p = pose_head.pnp
         sd = decode_kw.get('ref_length', 1.6) * decode_kw.get('ref_focal_y', 722) * decode_kw.get('target_std', 0.15)
-        ret_val, yaw, t_vec, cov, _, dims, dims_var, cov_calib = pnp_from_head(
+        ret_val, yaw, t_vec, cov, inlier_mask, dims, dims_var, cov_calib = pnp_from_head(
             all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape, std_scale=pose_head.std_scale,
             epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, allowed_border=pose_head.allowed_border,
             z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, inlier_opt_only=p.inlier_opt_only,
             cov_calib_logscale=pose_head.cov_calib_logscale, cov_correction_sd=sd if apply_cov_correction else 0.0, **decode_kw)
         return dict(ret_val=ret_val, yaw_pred=yaw, t_vec_pred=t_vec, pose_cov_pred=cov, pose_cov_calib=cov_calib,
-                    dimensions_pred=dims, dimensions_var=dims_var)      # calibration + distance correction done by the kernel
+                    dimensions_pred=dims, dimensions_var=dims_var, inlier_mask=inlier_mask)      # calibration + distance correction done by the kernel
     else:
         dec = noc_decode(all_pred, labels, flip, dim, dim_var, rois, std_scale=pose_head.std_scale,
                          epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, **decode_kw)
         img_shapes = torch.as_tensor(np.asarray(_hw_rows(img_shape.cpu() if torch.is_tensor(img_shape) else img_shape), np.float32), device=all_pred.device)
-        ret_val, yaw, t_vec, cov, cov_calib = pose_head.forward_decoded(dec, cam_intrinsic, img_shapes)
+        ret_val, yaw, t_vec, cov, cov_calib, inlier_mask = pose_head.forward_decoded(dec, cam_intrinsic, img_shapes, with_mask=True)
         dims, dims_var = dec['dims'], dec['dims_var']
     if apply_cov_correction:
         kw = {k: decode_kw[k] for k in ('ref_length', 'ref_focal_y', 'target_std') if k in decode_kw}
         cov_calib = cov_correction(cov_calib, t_vec, **kw)
     return dict(ret_val=ret_val, yaw_pred=yaw, t_vec_pred=t_vec, pose_cov_pred=cov, pose_cov_calib=cov_calib,
-                dimensions_pred=dims, dimensions_var=dims_var)
+                dimensions_pred=dims, dimensions_var=dims_var, inlier_mask=inlier_mask)

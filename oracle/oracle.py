@@ -300,7 +300,62 @@ def noc_decode(noc, dims, dims_var):
     return c3d, var
 
 
-def decode_logstd(proj_logstd, c3d_var, ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0):
+def spec_expf(x):
+    """float32 exp as SPECIFIED for the HIP decode (monorun_pnp.hip::mr_expf): the same sequence of IEEE float32 multiplications
+    and additions (numpy float32 arithmetic is exactly that), so the result is bit-identical to the kernel's."""
+    x = np.asarray(x, np.float32)
+    f = np.float32
+    with np.errstate(over='ignore', under='ignore', invalid='ignore'):
+        kf = np.rint(x * f(1.44269504088896341))
+        r = x - kf * f(0.693359375)
+        r = r - kf * f(-2.12194440e-4)
+        z = r * r
+        p = f(1.9875691500E-4) * r + f(1.3981999507E-3)
+        p = p * r + f(8.3334519073E-3)
+        p = p * r + f(4.1665795894E-2)
+        p = p * r + f(1.6666665459E-1)
+        p = p * r + f(5.0000001201E-1)
+        y = p * z + r
+        y = y + f(1.0)
+        k = np.where(np.isfinite(kf), kf, 0).astype(np.int32)
+        out = np.ldexp(y, k).astype(np.float32)
+    out = np.where(x > f(88.72283935546875), f(np.inf), out)
+    out = np.where(x < f(-103.0), f(0.0), out)
+    return out.astype(np.float32)
+
+
+def spec_logf(x):
+    """float32 log as SPECIFIED for the HIP decode (monorun_pnp.hip::mr_logf), operation for operation."""
+    x = np.asarray(x, np.float32)
+    f = np.float32
+    with np.errstate(all='ignore'):
+        m, e = np.frexp(x)
+        m = m.astype(np.float32)
+        lo = m < f(0.707106781186547524)
+        e = np.where(lo, e - 1, e)
+        m = np.where(lo, m + m - f(1.0), m - f(1.0)).astype(np.float32)
+        z = m * m
+        p = f(7.0376836292E-2) * m - f(1.1514610310E-1)
+        p = p * m + f(1.1676998740E-1)
+        p = p * m - f(1.2420140846E-1)
+        p = p * m + f(1.4249322787E-1)
+        p = p * m - f(1.6668057665E-1)
+        p = p * m + f(2.0000714765E-1)
+        p = p * m - f(2.4999993993E-1)
+        p = p * m + f(3.3333331174E-1)
+        fe = e.astype(np.float32)
+        y = m * (z * p)
+        y = y + f(-2.12194440e-4) * fe
+        y = y - f(0.5) * z
+        zz = m + y
+        out = (zz + f(0.693359375) * fe).astype(np.float32)
+    out = np.where(x == f(np.inf), f(np.inf), out)
+    out = np.where(x == 0, f(-np.inf), out)
+    out = np.where(~(x >= 0), f(np.nan), out)
+    return out.astype(np.float32)
+
+
+def decode_logstd(proj_logstd, c3d_var, ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0, exp=np.exp, log=np.log):
     """R11 (distance_invar_proj_error_coder.py:39-60) with distance=None."""
     sd = np.float32(ref_length * ref_focal_y * target_std)
     if c3d_var is None:
@@ -309,8 +364,8 @@ def decode_logstd(proj_logstd, c3d_var, ref_length=1.6, ref_focal_y=722, target_
     v2[:, 0] = np.float32(0.5) * (c3d_var[:, 0] + c3d_var[:, 2])
     v2[:, 1] = c3d_var[:, 1]
     v2 = (v2 * np.float32((ref_focal_y * epistemic_std_gain) ** 2)
-          + np.exp(np.float32(2) * proj_logstd) * np.float32(sd ** 2)) / np.square(sd)
-    return (np.float32(0.5) * np.log(v2)).astype(np.float32)
+          + exp(np.float32(2) * proj_logstd) * np.float32(sd ** 2)) / np.square(sd)
+    return (np.float32(0.5) * log(v2)).astype(np.float32)
 
 
 def roi_grid(rois_xyxy, h=28, w=28):
@@ -329,11 +384,11 @@ def roi_grid(rois_xyxy, h=28, w=28):
 
 
 def pose_head_prep(coords_2d, coords_2d_logstd, coords_3d, img_shapes, allowed_border=200,
-                   epnp_ransac_thres_ratio=0.2, std_scale=10):
+                   epnp_ransac_thres_ratio=0.2, std_scale=10, exp=np.exp):
     """R8 (uncert_prop_pnp_optimizer.py:73-88): NCHW maps -> the PnP boundary tensors, keeping the
     reference's *strided views* (permute(0,2,3,1).view -> strides (C*hw, 1, hw))."""
     bn, _, h, w = coords_2d.shape
-    istd = (np.exp(-coords_2d_logstd) / np.float32(std_scale)).astype(np.float32)
+    istd = (exp(-coords_2d_logstd) / np.float32(std_scale)).astype(np.float32)
     img_shapes = np.asarray(img_shapes, np.float32).reshape(-1, 2)
     u_range = np.full((img_shapes.shape[0], 2), -allowed_border, np.float32)
     v_range = np.full((img_shapes.shape[0], 2), -allowed_border, np.float32)

@@ -27,9 +27,15 @@ def test_k2_against_reference_decode_chain(dev, g3, orc):
     # integer channel pick + unfused fp32 mul/add chain: bit-exact against the reference's own output
     assert np.array_equal(c3d, g3['c3d'])
     assert np.array_equal(dec['dims'].cpu().numpy(), g3['dims']) and np.array_equal(dec['dims_var'].cpu().numpy(), g3['dims_var'])
-    # exp/log are library functions: a few ulp
+    # exp/log: the reference's torch.exp / torch.log are library routines (a few ulp from any other library) ...
     istd_ref = np.exp(-g3['logstd_px']) / np.float32(10)
     np.testing.assert_allclose(dec['coords_2d_istd'].cpu().numpy(), istd_ref, rtol=3e-6)
+    # ... the kernel's are SPECIFIED (mr_expf / mr_logf: fixed float32 operation sequences) and restated operation for operation
+    # in the oracle, so the decoded istd — which feeds a bit-exact threshold — is bit-identical
+    n_noc, n_ls, _ = orc.slice_pred(g3['all_pred'], g3['labels'], g3['flip'])
+    d_, dv_ = orc.dim_decode(g3['dim'], g3['dim_var'], g3['labels'])
+    ls_spec = orc.decode_logstd(n_ls, orc.noc_decode(n_noc, d_, dv_)[1], exp=orc.spec_expf, log=orc.spec_logf)
+    assert np.array_equal(dec['coords_2d_istd'].cpu().numpy(), orc.spec_expf(-ls_spec) / np.float32(10))
     grid = orc.roi_grid(rois)
     assert np.array_equal(dec['coords_2d'].cpu().numpy(), grid)
     thr_ref = np.float32(0.2) * (grid[:, 1, -1, 0] - grid[:, 1, 0, 0])
@@ -106,9 +112,10 @@ def test_tail_end_to_end_two_launches(dev, orc):
     # oracle chain (numpy restatement, pinned to the reference by the G3/G4 tests)
     n_noc, n_ls, _ = orc.slice_pred(all_pred, labels, flip)
     c3d, c3v = orc.noc_decode(n_noc, dims, dims_var)
-    ls_px = orc.decode_logstd(n_ls, c3v)
+    # exp / log as specified for the decode (bit-identical to the kernel's): the istd map, hence the thresholded mask, is exact
+    ls_px = orc.decode_logstd(n_ls, c3v, exp=orc.spec_expf, log=orc.spec_logf)
     c2d = orc.roi_grid(b['rois'])
-    x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(c2d, ls_px, c3d, b['img_shape'])
+    x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(c2d, ls_px, c3d, b['img_shape'], exp=orc.spec_expf)
     ref = orc.u2d_pnp(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
     logscale = np.array([0.3, -0.2, 0.1, 0.5], np.float32)
     ref_calib = orc.cov_correction(orc.cov_calib(ref[3], logscale), ref[2])
@@ -122,17 +129,18 @@ def test_tail_end_to_end_two_launches(dev, orc):
     torch.cuda.synchronize()
     # ONE fused launch == K2 followed by the PnP kernel, bit for bit (the calibrated covariance comes from the kernel's
     # epilogue in the fused path and from torch ops in the other: same float32 formula, ulp-level agreement)
-    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'dimensions_pred', 'dimensions_var'):
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'dimensions_pred', 'dimensions_var', 'inlier_mask'):
         assert torch.equal(res[k], res2[k]), k
     torch.testing.assert_close(res['pose_cov_calib'][res['ret_val']], res2['pose_cov_calib'][res2['ret_val']], rtol=2e-6, atol=0)
     assert np.array_equal(res['ret_val'].cpu().numpy(), ref[0])
     ok = ref[0]
-    # istd goes through exp/log (few-ulp differences) before the bit-exact-thresholded mask, so compare poses, not masks
-    assert np.abs(res['t_vec_pred'].cpu().numpy() - ref[2])[ok].max() <= 2e-3
+    # north-star bars on the whole head -> pose path: inlier masks bit-exact, rotation / translation within 1e-4
+    assert np.array_equal(res['inlier_mask'].cpu().numpy(), ref[5])
+    assert np.abs(res['t_vec_pred'].cpu().numpy() - ref[2])[ok].max() <= 1e-4
     dy = np.abs(np.angle(np.exp(1j * (res['yaw_pred'].cpu().numpy() - ref[1]))))[ok]
-    assert np.median(dy) <= 1e-5 and dy.max() <= 2e-3
+    assert dy.max() <= 1e-4
     rc = res['pose_cov_calib'].cpu().numpy()
-    assert np.median(np.abs(rc - ref_calib)[ok] / np.abs(ref_calib)[ok].max((1, 2), keepdims=True)) <= 1e-4
+    assert (np.abs(rc - ref_calib)[ok] / np.abs(ref_calib)[ok].max((1, 2), keepdims=True)).max() <= 1e-4
 
 
 def test_fused_head_to_pose_matches_two_launches_everywhere(dev, g3):
