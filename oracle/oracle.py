@@ -357,14 +357,15 @@ def spec_logf(x):
 
 def decode_logstd(proj_logstd, c3d_var, ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0, exp=np.exp, log=np.log):
     """R11 (distance_invar_proj_error_coder.py:39-60) with distance=None."""
-    sd = np.float32(ref_length * ref_focal_y * target_std)
+    sd_py = ref_length * ref_focal_y * target_std          # Python float: torch rounds `tensor * python_scalar` operands to float32
+    sd = np.float32(sd_py)                                 # new_tensor([scaling_denomitor]) (:41-42)
     if c3d_var is None:
         return proj_logstd + np.log(sd / sd)
     v2 = np.empty(proj_logstd.shape, np.float32)
     v2[:, 0] = np.float32(0.5) * (c3d_var[:, 0] + c3d_var[:, 2])
     v2[:, 1] = c3d_var[:, 1]
     v2 = (v2 * np.float32((ref_focal_y * epistemic_std_gain) ** 2)
-          + exp(np.float32(2) * proj_logstd) * np.float32(sd ** 2)) / np.square(sd)
+          + exp(np.float32(2) * proj_logstd) * np.float32(sd_py ** 2)) / np.square(sd)
     return (np.float32(0.5) * log(v2)).astype(np.float32)
 
 
