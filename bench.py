@@ -455,8 +455,9 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
 
 def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):
     """B = 100 proposals of one image: raw NOC-head output -> pose dict through the Python API (pose_from_head, fused: one
-    launch incl. decode, calibration, distance correction).  wall_us_per_call = host wall time per call with a stream
-    synchronise after every call (what a per-image pipeline sees); issue_us_per_call = back-to-back enqueue cost."""
+    launch incl. decode, calibration, distance correction), eagerly, through a prepared launch (PoseFromHeadLaunch: arguments built
+    once over static buffers) and as a HIP-graph replay of that launch.  wall_us_per_call_synced = host wall time per call with a
+    stream synchronise after every call (what a per-image pipeline sees); issue_us_per_call = back-to-back enqueue cost."""
     from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
     sub = {k: (v[:n_obj] if isinstance(v, np.ndarray) and v.shape[:1] == (batch0['labels'].shape[0],) else v) for k, v in batch0.items()}
     all_pred, dim = syn.encode_head_outputs(sub, seed=SEED)
@@ -468,15 +469,11 @@ def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):
     def call(**kw):
         with torch.no_grad():
             return pose_from_head(head, ap, lab, False, dm, None, rois, K, (syn.IMG_H, syn.IMG_W), **kw)
-    variants = {'eager': {}}
-    try:
-        from monorun_amd.pose_head import PoseFromHeadGraph   # hipGraph-captured prepared launch (when built)
-        g = PoseFromHeadGraph(head, ap, lab, False, dm, None, rois, K, (syn.IMG_H, syn.IMG_W))
-        variants['graph'] = g
-    except ImportError:
-        pass
-    for name, v in variants.items():
-        fn = call if name == 'eager' else v.replay
+    from monorun_amd.pose_head import PoseFromHeadLaunch
+    prepared = PoseFromHeadLaunch(head, ap, lab, False, dm, None, rois, K, (syn.IMG_H, syn.IMG_W))
+    graph = PoseFromHeadLaunch(head, ap, lab, False, dm, None, rois, K, (syn.IMG_H, syn.IMG_W)).capture()
+    variants = {'eager_pose_from_head': call, 'prepared_launch': prepared.run, 'hip_graph_replay': graph.replay}
+    for name, fn in variants.items():
         for _ in range(10):
             fn()
         torch.cuda.synchronize()
@@ -492,6 +489,9 @@ def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):
         torch.cuda.synchronize()
         thru = (time.perf_counter() - t1) / calls
         out[name] = {'wall_us_per_call_synced': wall * 1e6, 'issue_us_per_call': issue * 1e6, 'us_per_call_back_to_back': thru * 1e6}
+    ref = call()
+    for k in ('yaw_pred', 't_vec_pred', 'pose_cov_calib', 'inlier_mask'):      # the three paths are the same kernel on the same data
+        assert torch.equal(ref[k], prepared.out[k]) and torch.equal(ref[k], graph.out[k]), k
     res = call()
     out['objects'] = n_obj
     out['valid'] = int(res['ret_val'].sum().item())

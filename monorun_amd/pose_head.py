@@ -374,3 +374,86 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
         cov_calib = cov_correction(cov_calib, t_vec, **kw)
     return dict(ret_val=ret_val, yaw_pred=yaw, t_vec_pred=t_vec, pose_cov_pred=cov, pose_cov_calib=cov_calib,
                 dimensions_pred=dims, dimensions_var=dims_var, inlier_mask=inlier_mask)
+
+
+class PoseFromHeadLaunch:
+    """The per-image regime (monorun_roi_head.py:452: one image per forward, <= ~100 proposals): a PREPARED fused launch.
+
+    ``pose_from_head`` marshals ~60 ctypes arguments and allocates its outputs on every call (~40 us of host time, more than
+    the kernel itself takes at B = 100).  Here every argument is built once over static input / output tensors;
+    ``run()`` only enqueues the kernel on the current stream (a few us), and ``capture()`` records that launch into a HIP
+    graph (``torch.cuda.CUDAGraph``) whose ``replay()`` costs one graph launch.  Usage is the usual static-buffer pattern:
+    copy the new image's head output / labels / dims / RoIs into ``inputs`` (device-to-device, same stream), then
+    ``run()`` or ``replay()``; the results are the tensors in ``out`` (same keys as ``pose_from_head``).
+    Shapes (B, classes, h, w), the flip flag and the camera are fixed at construction."""
+
+    def __init__(self, pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape,
+                 apply_cov_correction=True, flags=0, num_classes=3, class_agnostic=False, dim_means=DIM_MEANS, dim_stds=DIM_STDS,
+                 noc_means=NOC_MEANS, noc_stds=NOC_STDS, ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0,
+                 coord_2d=None):
+        self.lib = _lib.load()
+        dev = all_pred.device
+        if dev.type != 'cuda':
+            raise RuntimeError('PoseFromHeadLaunch runs on an MI355X only (no CPU fallback)')
+        self.dev = dev
+        B, ch, h, w = all_pred.shape
+        Cn = 1 if class_agnostic else num_classes
+        assert ch == 2 * Cn * 5
+        f32 = dict(device=dev, dtype=torch.float32)
+        ap, ap_dt = _head_output(all_pred, dev)
+        r = rois.detach().to(**f32)
+        r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
+        self.inputs = dict(all_pred=ap, labels=labels.detach().to(device=dev, dtype=torch.int64).contiguous(), flip=_flip_flags(flip, B, dev).clone(),
+                           dim=dim.detach().to(**f32).contiguous(), dim_var=dim_var.detach().to(**f32).contiguous() if dim_var is not None else None,
+                           rois=r, cam_intrinsic=cam_intrinsic.detach().to(**f32).reshape(-1, 3, 3).contiguous())
+        ur, vr = _clip_ranges(img_shape, pose_head.allowed_border, dev)
+        mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
+        P = h * w
+        p = pose_head.pnp
+        self.out = dict(ret_val_u8=torch.empty(B, device=dev, dtype=torch.uint8), pose=torch.empty(B, 4, **f32), pose_cov_pred=torch.empty(B, 4, 4, **f32),
+                        tr_radius=torch.empty(B, **f32), inlier_mask_u8=torch.empty(B, P, device=dev, dtype=torch.uint8),
+                        dimensions_pred=torch.empty(B, 3, **f32), dimensions_var=torch.empty(B, 3, **f32) if dim_var is not None else None,
+                        pose_cov_calib=torch.empty(B, 4, 4, **f32))
+        o, i = self.out, self.inputs
+        o['ret_val'], o['inlier_mask'] = o['ret_val_u8'].view(torch.bool), o['inlier_mask_u8'].view(torch.bool)
+        o['yaw_pred'], o['t_vec_pred'] = o['pose'][:, :1], o['pose'][:, 1:]
+        self.logscale = pose_head.cov_calib_logscale.detach().to(**f32).contiguous()
+        sdv = ref_length * ref_focal_y * target_std
+        mp, mh, mw = _coord_map_args(coord_2d, dev)
+        self._keep = (ur, vr, mu, sd, nm, ns, coord_2d)
+        self.B = B
+        ratio = pose_head.epnp_ransac_thres_ratio
+        self.args = [i['all_pred'].data_ptr(), ap_dt, i['labels'].data_ptr(), i['flip'].data_ptr(), i['dim'].data_ptr(),
+                     i['dim_var'].data_ptr() if i['dim_var'] is not None else None, i['rois'].data_ptr(),
+                     B, num_classes, int(class_agnostic), h, w, mu.data_ptr(), sd.data_ptr(), nm.data_ptr(), ns.data_ptr(),
+                     float(sdv), float(ref_focal_y), float(epistemic_std_gain), float(pose_head.std_scale), float(ratio) if ratio is not None else -1.0,
+                     i['cam_intrinsic'].data_ptr(), i['cam_intrinsic'].shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                     float(p.z_min), float(p.epnp_istd_thres), int(bool(p.inlier_opt_only)), int(flags),
+                     o['ret_val_u8'].data_ptr(), o['pose'].data_ptr(), o['pose_cov_pred'].data_ptr(), o['tr_radius'].data_ptr(), o['inlier_mask_u8'].data_ptr(),
+                     None, o['dimensions_pred'].data_ptr(), o['dimensions_var'].data_ptr() if o['dimensions_var'] is not None else None, mp, mh, mw,
+                     self.logscale.data_ptr(), float(sdv) if apply_cov_correction else 0.0, o['pose_cov_calib'].data_ptr()]
+        self.graph = None
+
+    def run(self, stream=None):
+        if self.B:
+            st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+            code = self.lib.mr_pnp_from_head_batched(*self.args, st)
+            if code:
+                _lib.check(code)
+        return self.out
+
+    def capture(self):
+        """Record the launch into a HIP graph (one warm-up launch first: the LDS opt-in of the kernel is set outside the capture)."""
+        self.run()
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run()
+        self.graph = g
+        return self
+
+    def replay(self):
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        return self.out

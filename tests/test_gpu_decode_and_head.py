@@ -219,3 +219,32 @@ def test_half_precision_head_outputs(dev, g3, dtype):
     o1, o2 = pnp_from_head(ap_lo, *args, K, img), pnp_from_head(ap_32, *args, K, img)
     for x, y in zip(o1, o2):
         assert torch.equal(x, y)
+
+
+def test_prepared_and_graph_launch_for_the_per_image_regime(dev, orc):
+    """PoseFromHeadLaunch (arguments built once over static buffers; optionally a HIP-graph replay) gives exactly what
+    pose_from_head gives, also after the static inputs were overwritten with the next image's data."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head, PoseFromHeadLaunch
+    head = UncertPropPnPOptimizer().to(dev)
+    with torch.no_grad():
+        head.cov_calib_logscale.copy_(torch.tensor([0.2, -0.1, 0.0, 0.4]))
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    imgs = []
+    for seed in (3, 4):
+        b = syn.make_batch(B=60, seed=seed)
+        all_pred, dim = syn.encode_head_outputs(b, seed=seed)
+        imgs.append((t(all_pred), t(b['labels']), t(dim), t(b['rois']), t(b['K'])))
+    shape = (syn.IMG_H, syn.IMG_W, 3)                       # mmdet's img_meta['img_shape']
+    a0 = imgs[0]
+    prepared = PoseFromHeadLaunch(head, a0[0].clone(), a0[1].clone(), False, a0[2].clone(), None, a0[3].clone(), a0[4], shape)
+    graph = PoseFromHeadLaunch(head, a0[0].clone(), a0[1].clone(), False, a0[2].clone(), None, a0[3].clone(), a0[4], shape).capture()
+    for ap, lab, dim, rois, K in imgs:
+        with torch.no_grad():
+            ref = pose_from_head(head, ap, lab, False, dim, None, rois, K, shape)
+        for L, go in ((prepared, prepared.run), (graph, graph.replay)):
+            L.inputs['all_pred'].copy_(ap); L.inputs['labels'].copy_(lab); L.inputs['dim'].copy_(dim); L.inputs['rois'].copy_(rois)
+            out = go()
+            torch.cuda.synchronize()
+            for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'dimensions_pred', 'inlier_mask'):
+                assert torch.equal(out[k], ref[k]), k
+        assert int(ref['ret_val'].sum()) >= 55
