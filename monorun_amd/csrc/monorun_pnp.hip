@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) roi_align_avg_kernel(const float *in, con
 // mask, pnp_uncert_cpu.py:164-168), so its last bit must not depend on which libm / device library computed it.  Classical
 // single-precision algorithms (Cephes expf / logf: Cody-Waite reduction with the two-part ln 2, degree-5 / degree-8
 // polynomials) written as a fixed sequence of IEEE float32 multiplications and additions — no fma, no contraction — which the
-// oracle restates operation for operation with numpy float32 arithmetic (oracle.spec_expf / spec_logf).  Error <= 1 ulp.
+// test infrastructure restates operation for operation with numpy float32 arithmetic (spec_expf / spec_logf there).  Error <= 1 ulp.
 __device__ __forceinline__ float mr_expf(float x) {
 #pragma clang fp contract(off)
     if (x > 88.72283935546875f) return __int_as_float(0x7f800000);

@@ -149,3 +149,45 @@ def test_img_shape_and_flip_forms_the_pipeline_passes():
     assert ph._flip_flags(torch.tensor([False]), 1, cpu).tolist() == [0]
     with pytest.raises(AssertionError):
         ph._flip_flags([True, False], 3, cpu)
+
+
+def test_pose_stage_dump_hook_on_a_stand_in_roi_head(tmp_path):
+    """monorun_amd.integration.PoseStageDump wraps the four call sites of MonoRUnRoIHead.simple_test
+    (monorun_roi_head.py:442-547) and writes what tools/kitti_val.py reads.  mmdet is absent, so the hook is exercised on a
+    stand-in object with the same attribute structure and call order; the wrapped functions must behave as before."""
+    import types
+    from monorun_amd.integration import PoseStageDump
+    n, C = 5, 3
+    conv = torch.nn.Conv2d(4, 2 * C * 5, 1)
+
+    class Head:
+        def __init__(self):
+            self.noc_head = types.SimpleNamespace(conv_final=conv)
+            self.bbox_head = types.SimpleNamespace(get_bboxes=lambda *a, **k: (torch.cat([torch.rand(n, 4) * 100, torch.rand(n, 1)], 1), torch.arange(n) % C))
+            self.score_head = types.SimpleNamespace(pre_sigmoid=True)
+            self.test_cfg = types.SimpleNamespace(mult_2d_score=True)
+
+        def _reg_forward(self, x, rois, labels):
+            return dict(dim_pred=torch.randn(len(rois), 3), dim_var=torch.rand(len(rois), 3))
+
+        def _score_forward(self, *a):
+            return dict(scores=torch.randn(n, 1))
+
+        def simple_test(self, x, proposal_list, img_metas, proposals=None, coord_2d=None, cam_intrinsic=None, rescale=False):
+            det_bboxes, det_labels = self.bbox_head.get_bboxes()
+            rois = torch.cat([torch.zeros(n, 1), det_bboxes[:, :4]], 1)
+            self._reg_forward(x, rois, det_labels)
+            self.noc_head.conv_final(torch.randn(n, 4, 28, 28))
+            self._score_forward()
+            return 'results'
+    h = Head()
+    orig = h.simple_test
+    meta = dict(filename='/data/kitti/training/image_2/000123.png', img_shape=(375, 1242, 3), flip=False)
+    with PoseStageDump(h, str(tmp_path)) as d:
+        assert h.simple_test(None, None, [meta], cam_intrinsic=[[torch.eye(3)]]) == 'results'
+    assert h.simple_test.__func__ is orig.__func__ and d.written == [str(tmp_path / '000123.npz')]       # restored on exit
+    z = np.load(d.written[0])
+    assert z['all_pred'].shape == (n, 30, 28, 28) and z['labels'].dtype == np.int64 and z['rois'].shape == (n, 4)
+    assert z['dim'].shape == (n, 3) and z['dim_var'].shape == (n, 3) and z['bboxes'].shape == (n, 4) and z['scores'].shape == (n,)
+    assert z['scores_ref'].shape == (n,) and np.all((z['scores_ref'] >= 0) & (z['scores_ref'] <= 1)) and z['img_shape'].tolist() == [375.0, 1242.0]
+    assert np.array_equal(z['rois'], z['bboxes']) and z['cam_intrinsic'].shape == (3, 3) and not bool(z['flip'])

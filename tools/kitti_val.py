@@ -62,9 +62,16 @@ def run_image(head, dump, K, img_shape, dev):
     labels = t(dump['labels'], torch.int64)
     if n == 0:
         return dict(bbox_results=[np.zeros((0, 5), np.float32) for _ in CLASSES], bbox_3d_results=[np.zeros((0, 8), np.float32) for _ in CLASSES])
-    res = pose_from_head(head, t(dump['all_pred']), labels, False, t(dump['dim']), t(dump['dim_var']) if 'dim_var' in dump else None,
+    # dumps written by monorun_amd.integration.PoseStageDump also carry the image's flip flag, its own camera and the reference's
+    # final scores (score head x class score): use them when present
+    flip = bool(dump['flip']) if 'flip' in dump else False
+    if 'cam_intrinsic' in dump:
+        K = t(np.asarray(dump['cam_intrinsic']).reshape(1, 3, 3))
+    if 'img_shape' in dump:
+        img_shape = tuple(float(v) for v in np.asarray(dump['img_shape']).reshape(-1)[:2])
+    res = pose_from_head(head, t(dump['all_pred']), labels, flip, t(dump['dim']), t(dump['dim_var']) if 'dim_var' in dump else None,
                          t(dump['rois']), K, img_shape)
-    scores = t(dump['scores']) * res['ret_val'].float()           # failed solves drop to score 0
+    scores = t(dump['scores_ref'] if 'scores_ref' in dump else dump['scores']) * res['ret_val'].float()           # failed solves drop to score 0
     b3 = get_bbox_3d_result(res['dimensions_pred'], res['yaw_pred'], res['t_vec_pred'], scores, labels, len(CLASSES), to_np=True)
     b2 = np.concatenate([np.asarray(dump['bboxes'], np.float32).reshape(n, 4), np.asarray(dump['scores'], np.float32).reshape(n, 1)], 1)
     lab = np.asarray(dump['labels'])
