@@ -112,6 +112,23 @@ int mr_pnp_uncert_batched(
     void *stream);
 
 /*
+ * True 6-DoF refinement (the flag the reference declares and ignores: `use_6dof`, pnp_uncert.py:11).
+ * Second launch of pnp_uncert(..., use_6dof=True): for each object, starting from the 4-DoF result pose4 = [yaw,tx,ty,tz]
+ * (r = (0,yaw,0)) on the points of that solve's final inlier_mask, the same residual functor (pnp_uncert_cpu.cpp:24-51) is
+ * minimised over pose6 = [rx,ry,rz,tx,ty,tz] (angle-axis) with the same Ceres-1.14 LM; cov6 = (J^T J)^-1 (6x6, row-major)
+ * with the solver's Jacobian at the returned pose.  Inputs / strides / cameras / ranges as for mr_pnp_uncert_batched;
+ * inlier_mask (B,P) u8, pose4 (B,4) f32, valid4 (B) u8 = outputs of that call.  Outputs: valid (B) u8, pose6 (B,6) f32,
+ * cov6 (B,36) f32 (identity when invalid), diag (B,2) f32 [LM iterations, exit reason as MR_DIAG_WHY] or NULL.
+ * flags: only the MR_LM_MAXIT bits are read.
+ */
+int mr_pnp6_refine_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const uint8_t *inlier_mask, const float *pose4, const uint8_t *valid4, int B, int P, float z_min, int flags,
+    uint8_t *valid, float *pose6, float *cov6, float *diag, void *stream);
+
+/*
  * The reference's own per-object C entry point, same signature and semantics (ext.h:1-13,
  * pnp_uncert_cpu.cpp:245-292): HOST fp64 buffers in, host results out; runs the same LM kernel on the
  * GPU for one object (blocking).  result_cov may be NULL; on failure result_cov is left untouched.

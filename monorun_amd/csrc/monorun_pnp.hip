@@ -272,6 +272,7 @@ struct PnpArgs {
 };
 
 #include "pnp_kernel.inc"
+#include "pnp6_kernel.inc"
 #include "pnp_noc_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -502,6 +503,21 @@ int pick_wpo(int B, int P, int flags) {
     return w;
 }
 
+// 6-DoF refinement (second launch of pnp_uncert(..., use_6dof=True)): see pnp6_kernel.inc
+template <typename T>
+int launch_pnp6(Pnp6Args &a, hipStream_t st) {
+    a.elem_size = (int)sizeof(T);
+    a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
+    const int nchunk = (a.P + 63) / 64;
+    const size_t lds = sizeof(double) * 2 * 4 * kRedN + sizeof(unsigned long long) * ((nchunk + 3) & ~3) + (size_t)8 * a.P * sizeof(T) +
+                       sizeof(uint16_t) * ((a.P + 7) & ~7) + 16;
+    if (lds > 160 * 1024) return MR_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pnp6_refine_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((pnp6_refine_kernel<T>), dim3(a.B), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
 }  // namespace
 
 // ================================================================================= C ABI =========
@@ -566,6 +582,36 @@ int mr_pnp_uncert_batched(
         case MR_F32: return launch_wpo<float>(a, wpo, st);
         case MR_F16: return launch_wpo<__half>(a, wpo, st);
         case MR_F64: return launch_wpo<double>(a, wpo, st);
+        default: return MR_ERR_UNSUPPORTED;
+    }
+}
+
+int mr_pnp6_refine_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const uint8_t *inlier_mask, const float *pose4, const uint8_t *valid4, int B, int P, float z_min, int flags,
+    uint8_t *valid, float *pose6, float *cov6, float *diag, void *stream) {
+    if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !inlier_mask || !pose4 ||
+        !valid4 || !valid || !pose6 || !cov6)
+        return MR_ERR_BAD_ARGUMENT;
+    if ((cam_batch != 1 && cam_batch != B) || (range_batch != 1 && range_batch != B)) return MR_ERR_BAD_ARGUMENT;
+    Pnp6Args a;
+    memset(&a, 0, sizeof a);
+    a.x2d = x2d; a.istd = istd; a.x3d = x3d;
+    for (int i = 0; i < 3; ++i) { a.s2[i] = x2d_strides[i]; a.sw[i] = istd_strides[i]; a.s3[i] = x3d_strides[i]; }
+    a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
+    a.ur = u_range; a.vr = v_range; a.r_stride = (range_batch == 1) ? 0 : 2; a.r_f64 = 0;
+    a.mask = inlier_mask; a.pose4 = pose4; a.valid4 = valid4;
+    a.B = B; a.P = P; a.z_min = (double)z_min;
+    { const int mi = (flags & MR_LM_MAXIT_MASK) >> MR_LM_MAXIT_SHIFT; a.lm_max_iter = mi ? mi : 50; }
+    a.valid = valid; a.pose6 = pose6; a.cov6 = cov6; a.diag = diag;
+    switch (in_dtype) {
+        case MR_F32: return launch_pnp6<float>(a, (hipStream_t)stream);
+        case MR_F16: return launch_pnp6<__half>(a, (hipStream_t)stream);
+        case MR_F64: return launch_pnp6<double>(a, (hipStream_t)stream);
         default: return MR_ERR_UNSUPPORTED;
     }
 }

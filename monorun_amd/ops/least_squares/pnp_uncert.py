@@ -114,6 +114,35 @@ class PnPLaunch:
             _lib.check(code)
 
 
+def pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, inlier_mask_u8, pose4, valid4_u8, z_min=0.5,
+                       flags=0, with_diag=False):
+    """Second launch of the 6-DoF mode (``mr_pnp6_refine_batched``): 6-DoF LM from the 4-DoF result on its inlier set.
+    Returns (valid u8 (B,), pose6 f32 (B,6) [rx,ry,rz,tx,ty,tz], cov6 f32 (B,6,6), diag f32 (B,2)|None)."""
+    lib = _lib.load()
+    dev = coords_2d.device
+    B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+    dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
+    prep = lambda t: t.detach() if (t.dtype == dt and t.device == dev) else t.detach().to(device=dev, dtype=dt)
+    x2d, istd, x3d = prep(coords_2d), prep(coords_2d_istd), prep(coords_3d)
+    f32 = dict(device=dev, dtype=torch.float32)
+    cam = cam_mats.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    ur = u_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    vr = v_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    pose6 = torch.empty(B, 6, **f32)
+    cov6 = torch.empty(B, 6, 6, **f32)
+    diag = torch.empty(B, 2, **f32) if with_diag else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_pnp6_refine_batched(
+                x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt],
+                cam.data_ptr(), cam.shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                inlier_mask_u8.contiguous().data_ptr(), pose4.contiguous().data_ptr(), valid4_u8.contiguous().data_ptr(), B, P, float(z_min), int(flags),
+                valid.data_ptr(), pose6.data_ptr(), cov6.data_ptr(), diag.data_ptr() if diag is not None else None,
+                torch.cuda.current_stream(dev).cuda_stream))
+    return valid, pose6, cov6, diag
+
+
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
                epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False):
     """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
@@ -121,9 +150,14 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     coords_2d / coords_2d_istd (B,P,2), coords_3d (B,P,3), cam_mats (B|1,3,3), u_range / v_range (B|1,2),
     epnp_ransac_thres (B,) or None — any device; host tensors are staged through the GPU.
     forward_exact_hessian: only False (every shipped config, e.g. configs/kitti_car.py:123; the reference's exact Hessian no
-    longer runs on torch >= 2).  use_6dof: accepted and ignored, exactly as in the reference (pnp_uncert.py:11).
-    Returns (ret_val (B,) bool, r_vec (B,1) yaw, t_vec (B,3), pose_cov (B,4,4) covariance of [yaw, t], inlier_mask (B,P) bool)
-    on the device and in the dtype of coords_2d.
+    longer runs on torch >= 2).
+    use_6dof=False (every shipped config): returns (ret_val (B,) bool, r_vec (B,1) yaw, t_vec (B,3), pose_cov (B,4,4) covariance of
+    [yaw, t], inlier_mask (B,P) bool) on the device and in the dtype of coords_2d — the reference's tuple.
+    use_6dof=True: the flag the reference declares and never reads (pnp_uncert.py:11) made real — after the 4-DoF solve (mask,
+    initial pose) a second launch refines all six pose parameters with the same residual and LM: r_vec becomes the (B,3)
+    angle-axis vector, pose_cov the (B,6,6) covariance of [rx, ry, rz, tx, ty, tz] (solver Jacobian); ret_val additionally
+    requires the 6-DoF solve to be usable.  Because the flag is dead in the reference, every shipped config keeps running
+    the 4-DoF path.
     """
     if forward_exact_hessian:
         raise NotImplementedError('forward_exact_hessian=True is not supported (unused by every reference config)')
@@ -139,6 +173,10 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
             coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=z_min,
             epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres, inlier_opt_only=inlier_opt_only)
         odt = coords_2d.dtype
+        if use_6dof:
+            valid6, pose6, cov6, _ = pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, mask, pose, valid, z_min=z_min)
+            return ((valid & valid6).to(device=src_dev, dtype=torch.bool), pose6[:, :3].to(device=src_dev, dtype=odt),
+                    pose6[:, 3:].to(device=src_dev, dtype=odt), cov6.to(device=src_dev, dtype=odt), mask.to(device=src_dev, dtype=torch.bool))
         ret_val = valid.to(device=src_dev, dtype=torch.bool)
         r_vec = pose[:, :1].to(device=src_dev, dtype=odt)
         t_vec = pose[:, 1:].to(device=src_dev, dtype=odt)

@@ -254,6 +254,40 @@ def cv_rng_uniform(seed, count, a, b):
     return out
 
 
+def pnp6_uncert(pts2d, pts3d, wgt2d, K, init_pose6, clips):
+    """6-DoF solve of one object (host fp64): returns dict(val, pose (6,), cov (6,6), tr, iters, why)."""
+    pts2d, pts3d, wgt2d, K, init_pose6, clips = map(_d, (pts2d, pts3d, wgt2d, K, init_pose6, clips))
+    val, pose, cov, tr, diag = np.zeros(1, np.int32), np.zeros(6), np.eye(6), np.zeros(1), np.zeros(5)
+    lib().orc_pnp6_uncert(_p(pts2d, c_dp), _p(pts3d, c_dp), _p(wgt2d, c_dp), _p(K, c_dp), _p(init_pose6, c_dp), _p(val, c_ip), _p(pose, c_dp),
+                          _p(cov, c_dp), _p(tr, c_dp), ctypes.c_int(pts2d.shape[0]), _p(clips, c_dp), _p(diag, c_dp))
+    return dict(val=int(val[0]), pose=pose, cov=cov, tr=float(tr[0]), iters=int(diag[0]), why=int(diag[1]), final_cost=diag[4])
+
+
+def eval6(pts2d, pts3d, wgt2d, K, pose6, clips):
+    """cost, gradient (6,), J^T J (6,6), residuals (pn,2), Jacobian (pn,2,6) of the 6-DoF problem at pose6 (Ceres / Jet semantics)."""
+    pts2d, pts3d, wgt2d, K, pose6, clips = map(_d, (pts2d, pts3d, wgt2d, K, pose6, clips))
+    pn = pts2d.shape[0]
+    cost, g, H, res, jac = np.zeros(1), np.zeros(6), np.zeros((6, 6)), np.zeros((pn, 2)), np.zeros((pn, 2, 6))
+    f = lib().orc_eval6
+    f.restype = ctypes.c_int
+    ok = f(_p(pts2d, c_dp), _p(pts3d, c_dp), _p(wgt2d, c_dp), _p(K, c_dp), _p(pose6, c_dp), ctypes.c_int(pn), _p(clips, c_dp), _p(cost, c_dp), _p(g, c_dp),
+           _p(H, c_dp), _p(res, c_dp), _p(jac, c_dp))
+    return bool(ok), float(cost[0]), g, H, res, jac
+
+
+def pnp6_refine(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, mask, pose4, valid4, z_min=0.5, num_threads=1):
+    """Batch 6-DoF refinement from the 4-DoF result on its inlier mask: returns (valid (B,), pose6 (B,6) f32, cov6 (B,6,6) f32, diag (B,2))."""
+    B, P = coords_2d.shape[:2]
+    x2d, istd, x3d = _f(coords_2d), _f(coords_2d_istd), _f(coords_3d)
+    K = _f(cam_mats).reshape(-1, 9); ur, vr = _f(u_range).reshape(-1, 2), _f(v_range).reshape(-1, 2)
+    m = np.ascontiguousarray(mask, np.uint8); p4 = _f(pose4).reshape(B, 4); v4 = np.ascontiguousarray(valid4, np.uint8)
+    valid, pose6, cov6, diag = np.zeros(B, np.uint8), np.zeros((B, 6), np.float32), np.zeros((B, 36), np.float32), np.zeros((B, 2), np.float32)
+    lib().orc_pnp6_refine_batch(_p(x2d, c_fp), _p(istd, c_fp), _p(x3d, c_fp), _p(K, c_fp), ctypes.c_int(K.shape[0]), _p(ur, c_fp), _p(vr, c_fp),
+                                ctypes.c_int(ur.shape[0]), _p(m, c_u8p), _p(p4, c_fp), _p(v4, c_u8p), ctypes.c_int(B), ctypes.c_int(P),
+                                ctypes.c_double(z_min), ctypes.c_int(num_threads), _p(valid, c_u8p), _p(pose6, c_fp), _p(cov6, c_fp), _p(diag, c_fp))
+    return valid.astype(bool), pose6, cov6.reshape(B, 6, 6), diag
+
+
 def max_threads():
     return int(lib().orc_max_threads())
 

@@ -57,6 +57,13 @@
 #undef JN
 #undef JET
 #undef JF
+#define JN 6
+#define JET jet6
+#define JF(name) j6_##name
+#include "jet.inc"
+#undef JN
+#undef JET
+#undef JF
 
 /* ------------------------------------------------------------------------------------------
  * R1: ReprojectionErrorArray::operator() on Jets (pnp_uncert_cpu.cpp:24-51).
@@ -739,6 +746,117 @@ int orc_k0_init(const float *x2d /*pn,2*/, const float *x3d /*pn,3*/, uint8_t *m
     }
     free(list);
     return ok;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * N4 remainder: a TRUE 6-DoF variant — what `use_6dof=True` would mean (pnp_uncert.py:11 accepts the flag and ignores it; the
+ * north-star's "6x6 normal equations").  No reference code exists for it: the SAME residual functor as R1
+ * (pnp_uncert_cpu.cpp:24-51) with the full angle-axis vector r = (rx, ry, rz) in ceres::AngleAxisRotatePoint instead of
+ * (0, yaw, 0), pose6 = [rx, ry, rz, tx, ty, tz], Jets with 6 partials, the same Ceres-1.14 LM, covariance = (J^T J)^-1 with
+ * the solver's Jacobian.  Pinned by finite differences and scipy (tests/test_pnp6.py).
+ * ---------------------------------------------------------------------------------------- */
+static void orc_residual_jet6(const orc_cam *c, const double pose[6], double x2d, double y2d, double x3d, double y3d, double z3d,
+                              double wxx, double wyy, double res[2], double jac[12]) {
+    jet6 p[6]; for (int i = 0; i < 6; ++i) p[i] = j6_var(pose[i], i);
+    jet6 pts3d[3] = { j6_const(x3d), j6_const(y3d), j6_const(z3d) };
+    jet6 r_vec[3] = { p[0], p[1], p[2] };
+    jet6 t[3];
+    j6_angle_axis_rotate_point(r_vec, pts3d, t);
+    t[0] = j6_add(t[0], p[3]); t[1] = j6_add(t[1], p[4]); t[2] = j6_add(t[2], p[5]);
+    if (t[2].a < c->z_min) t[2] = j6_const(c->z_min);
+    jet6 proj_x = j6_add(j6_div(j6_mul(j6_const(c->fx), t[0]), t[2]), j6_const(c->cx));
+    jet6 proj_y = j6_add(j6_div(j6_mul(j6_const(c->fy), t[1]), t[2]), j6_const(c->cy));
+    if (proj_x.a < c->u_min) proj_x = j6_const(c->u_min); else if (proj_x.a > c->u_max) proj_x = j6_const(c->u_max);
+    if (proj_y.a < c->v_min) proj_y = j6_const(c->v_min); else if (proj_y.a > c->v_max) proj_y = j6_const(c->v_max);
+    jet6 r0 = j6_mul(j6_const(wxx), j6_sub(proj_x, j6_const(x2d)));
+    jet6 r1 = j6_mul(j6_const(wyy), j6_sub(proj_y, j6_const(y2d)));
+    res[0] = r0.a; res[1] = r1.a;
+    for (int i = 0; i < 6; ++i) { jac[i] = r0.v[i]; jac[6 + i] = r1.v[i]; }
+}
+static int orc_eval6_cb(const void *ctx, const double *x, double *cost, double *g, double *H) {
+    const orc_problem *pb = (const orc_problem *)ctx;
+    double c = 0.0, gg[6] = {0, 0, 0, 0, 0, 0}, HH[36]; memset(HH, 0, sizeof HH);
+    for (int i = 0; i < pb->pn; ++i) {
+        double r[2], J[12];
+        orc_residual_jet6(&pb->cam, x, pb->pts2d[2 * i], pb->pts2d[2 * i + 1], pb->pts3d[3 * i], pb->pts3d[3 * i + 1], pb->pts3d[3 * i + 2],
+                          pb->wgt2d[2 * i], pb->wgt2d[2 * i + 1], r, J);
+        c += r[0] * r[0] + r[1] * r[1];
+        for (int a = 0; a < 6; ++a) { gg[a] += J[a] * r[0] + J[6 + a] * r[1];
+            for (int b = 0; b < 6; ++b) HH[6 * a + b] += J[a] * J[b] + J[6 + a] * J[6 + b]; }
+    }
+    *cost = 0.5 * c;
+    int ok = isfinite(*cost);
+    for (int a = 0; a < 6; ++a) { g[a] = gg[a]; ok = ok && isfinite(gg[a]); }
+    for (int a = 0; a < 36; ++a) { H[a] = HH[a]; ok = ok && isfinite(HH[a]); }
+    return ok;
+}
+static int orc_spd_inverse_n(int n, const double *H, double *inv) {
+    for (int c = 0; c < n; ++c) {
+        double e[ORC_MAXN] = {0}, x[ORC_MAXN]; e[c] = 1.0;
+        if (!orc_chol_solve(n, H, e, x)) return 0;
+        for (int r = 0; r < n; ++r) inv[n * r + c] = x[r];
+    }
+    for (int i = 0; i < n * n; ++i) if (!isfinite(inv[i])) return 0;
+    return 1;
+}
+/* one object, host fp64 buffers (the 6-DoF analogue of ext.h's pnp_uncert); diag: iters, why, termination, init/final cost */
+void orc_pnp6_uncert(double *pts2d, double *pts3d, double *wgt2d, double *K, double *init_pose6, int *result_val, double *result_pose6,
+                     double *result_cov36, double *result_tr, int pn, double *clips, double *diag) {
+    orc_problem pb;
+    pb.cam.fx = K[0]; pb.cam.fy = K[4]; pb.cam.cx = K[2]; pb.cam.cy = K[5];
+    pb.cam.z_min = clips[0]; pb.cam.u_min = clips[1]; pb.cam.u_max = clips[2]; pb.cam.v_min = clips[3]; pb.cam.v_max = clips[4];
+    pb.pn = pn; pb.pts2d = pts2d; pb.pts3d = pts3d; pb.wgt2d = wgt2d;
+    orc_lm_summary sm;
+    orc_lm_n(6, orc_eval6_cb, &pb, init_pose6, result_pose6, &sm);
+    *result_val = (sm.termination == ORC_CONVERGENCE || sm.termination == ORC_NO_CONVERGENCE) ? 1 : 0;
+    *result_tr = sm.radius;
+    if (diag) { diag[0] = sm.num_iterations; diag[1] = sm.why; diag[2] = sm.termination; diag[3] = sm.initial_cost; diag[4] = sm.final_cost; }
+    if (*result_val && result_cov36) {
+        double cost, g[6], H[36], inv[36];
+        int ok = orc_eval6_cb(&pb, result_pose6, &cost, g, H) && orc_spd_inverse_n(6, H, inv);
+        *result_val = ok ? 1 : 0;
+        if (ok) memcpy(result_cov36, inv, sizeof inv);
+    }
+}
+int orc_eval6(double *pts2d, double *pts3d, double *wgt2d, double *K, double *pose6, int pn, double *clips, double *cost, double *g, double *H,
+              double *res /* nullable pn*2 */, double *jac /* nullable pn*12 */) {
+    orc_problem pb;
+    pb.cam.fx = K[0]; pb.cam.fy = K[4]; pb.cam.cx = K[2]; pb.cam.cy = K[5];
+    pb.cam.z_min = clips[0]; pb.cam.u_min = clips[1]; pb.cam.u_max = clips[2]; pb.cam.v_min = clips[3]; pb.cam.v_max = clips[4];
+    pb.pn = pn; pb.pts2d = pts2d; pb.pts3d = pts3d; pb.wgt2d = wgt2d;
+    if (res && jac) for (int i = 0; i < pn; ++i)
+        orc_residual_jet6(&pb.cam, pose6, pts2d[2 * i], pts2d[2 * i + 1], pts3d[3 * i], pts3d[3 * i + 1], pts3d[3 * i + 2], wgt2d[2 * i], wgt2d[2 * i + 1], res + 2 * i, jac + 12 * i);
+    return orc_eval6_cb(&pb, pose6, cost, g, H);
+}
+/* batch refinement as the product's two-launch path does it: for each object the 6-DoF LM starts from the 4-DoF result
+ * (r = (0, yaw, 0), t) on the points of the final inlier mask; outputs float32 pose6 (B,6), cov6 (B,36), valid (B). */
+void orc_pnp6_refine_batch(const float *x2d, const float *istd, const float *x3d, const float *K, int Kb, const float *u_range, const float *v_range, int Rb,
+                           const uint8_t *mask, const float *pose4, const uint8_t *valid4, int B, int P, double z_min, int num_threads,
+                           uint8_t *valid, float *pose6, float *cov6, float *diag /* nullable B,2: iters, why */) {
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#pragma omp parallel for schedule(dynamic, 4) if (num_threads != 1)
+#endif
+    for (int b = 0; b < B; ++b) {
+        double *b2 = (double *)malloc(sizeof(double) * (size_t)P * 7), *b3 = b2 + 2 * (size_t)P, *bw = b3 + 3 * (size_t)P;
+        int m = 0;
+        for (int p = 0; p < P; ++p) if (mask[(size_t)b * P + p]) { const size_t q = (size_t)b * P + p;
+            b2[2 * m] = x2d[2 * q]; b2[2 * m + 1] = x2d[2 * q + 1]; b3[3 * m] = x3d[3 * q]; b3[3 * m + 1] = x3d[3 * q + 1]; b3[3 * m + 2] = x3d[3 * q + 2];
+            bw[2 * m] = istd[2 * q]; bw[2 * m + 1] = istd[2 * q + 1]; ++m; }
+        const float *Kf = K + (Kb == 1 ? 0 : (size_t)b * 9), *ur = u_range + (Rb == 1 ? 0 : (size_t)b * 2), *vr = v_range + (Rb == 1 ? 0 : (size_t)b * 2);
+        double Kd[9]; for (int i = 0; i < 9; ++i) Kd[i] = Kf[i];
+        double clips[5] = { z_min, ur[0], ur[1], vr[0], vr[1] };
+        double init[6] = { 0.0, pose4[4 * b], 0.0, pose4[4 * b + 1], pose4[4 * b + 2], pose4[4 * b + 3] }, out[6], cov[36], tr, dg[5] = {0, 0, 0, 0, 0};
+        int val = 0;
+        for (int i = 0; i < 36; ++i) cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        memcpy(out, init, sizeof out);
+        if (valid4[b] && m > 0) orc_pnp6_uncert(b2, b3, bw, Kd, init, &val, out, cov, &tr, m, clips, dg);
+        valid[b] = (uint8_t)val;
+        for (int i = 0; i < 6; ++i) pose6[6 * b + i] = valid4[b] ? (float)out[i] : 0.0f;
+        for (int i = 0; i < 36; ++i) cov6[36 * (size_t)b + i] = (float)cov[i];
+        if (diag) { diag[2 * b] = (float)dg[0]; diag[2 * b + 1] = (float)dg[1]; }
+        free(b2);
+    }
 }
 
 #include "epnp.inc"     /* the reference's own initialiser restated: EPnP inside OpenCV's RANSAC loop */
