@@ -259,6 +259,18 @@ void pnp_noc_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim,
 void pnp_noc_cov_uncert(double *pts2d, double *pts3d, double *wgt2d, double *logdim, double *logdim_wgt, double *K,
                         double *init_dimpose, int *result_val, double *result_dimpose, int pn, double *clips, double delta);
 
+/*
+ * Batched form of the two solvers above: B objects with pn correspondences each, DEVICE fp64 buffers, one workgroup per
+ * object, asynchronous on `stream`.  full_cov 0 = pnp_noc_uncert (wgt2d (B,pn,2)), 1 = pnp_noc_cov_uncert (wgt2d (B,pn,3)).
+ * pts2d (B,pn,2), pts3d (B,pn,3) NOC coordinates, logdim / logdim_wgt (B,3), K (K_batch,9) and clips (clips_batch,5) with
+ * batch 1 (shared) or B, init_dimpose (B,7).  Outputs: result_dimpose (B,7), result_val (B) int32 in {0,1}, diag (B,2)
+ * [LM iterations, final robustified cost] or NULL.
+ */
+int mr_pnp_noc_batched(int full_cov, const double *pts2d, const double *pts3d, const double *wgt2d, const double *logdim,
+                       const double *logdim_wgt, const double *K, int K_batch, const double *init_dimpose, const double *clips,
+                       int clips_batch, double delta, int B, int pn, double *result_dimpose, int32_t *result_val, double *diag,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,8 @@ def load():
         f = getattr(lib, name)
         f.restype = None
         f.argtypes = [dp, dp, dp, dp, dp, dp, dp, ctypes.POINTER(i32), dp, i32, dp, ctypes.c_double]
+    lib.mr_pnp_noc_batched.restype = i32
+    lib.mr_pnp_noc_batched.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, ctypes.c_double, i32, i32, vp, vp, vp, vp]
     lib.mr_nms_bev_batched.restype = i32
     lib.mr_nms_bev_batched.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
     i64 = ctypes.c_int64
@@ -116,5 +118,5 @@ def check(code):
 
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
-                    'mr_pnp_uncert_batched', 'mr_pnp6_refine_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert',
+                    'mr_pnp_uncert_batched', 'mr_pnp6_refine_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
                     'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

@@ -274,6 +274,7 @@ struct PnpArgs {
 #include "pnp_kernel.inc"
 #include "pnp6_kernel.inc"
 #include "pnp_noc_kernel.inc"
+constexpr size_t kNocLds = sizeof(double) * (2 * 4 * kRedN + 2 * 40);     // reduction scratch + two sets of block sums
 
 // ------------------------------------------------------------------------------------------------
 // N1: rotated-BEV NMS, the consumer that follows the PnP (monorun_roi_head.py:619-655 calls
@@ -791,6 +792,23 @@ int mr_kitti_match(int second_pass, int metric, int compute_aos, int alpha32, in
     return MR_OK;
 }
 
+// Batched form of the two 7-parameter solvers (device fp64 buffers, one workgroup per object; pnp_noc_kernel.inc)
+int mr_pnp_noc_batched(int full_cov, const double *pts2d, const double *pts3d, const double *wgt2d, const double *logdim, const double *logdim_wgt,
+                       const double *K, int K_batch, const double *init_dimpose, const double *clips, int clips_batch, double delta, int B, int pn,
+                       double *result_dimpose, int32_t *result_val, double *diag, void *stream) {
+    if (B < 0 || pn < 0 || (K_batch != 1 && K_batch != B) || (clips_batch != 1 && clips_batch != B)) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if ((pn > 0 && (!pts2d || !pts3d || !wgt2d)) || !logdim || !logdim_wgt || !K || !init_dimpose || !clips || !result_dimpose || !result_val) return MR_ERR_BAD_ARGUMENT;
+    NocArgs a;
+    memset(&a, 0, sizeof a);
+    a.pts2d = pts2d; a.pts3d = pts3d; a.wgt2d = wgt2d; a.logdim = logdim; a.logdim_wgt = logdim_wgt; a.K = K; a.init = init_dimpose; a.clips = clips;
+    a.K_batch = K_batch; a.clips_batch = clips_batch; a.delta = delta; a.pn = pn; a.full_cov = full_cov ? 1 : 0; a.B = B;
+    a.out_dimpose = result_dimpose; a.out_val = (int *)result_val; a.out_diag = diag;
+    hipLaunchKernelGGL(pnp_noc_kernel, dim3(B), dim3(256), kNocLds, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
 // ---- host-buffer entry points of the reference's C ABI (ext.h).  Per device: one private non-blocking stream, one pinned
 // host staging buffer and one device buffer, grown on demand and kept; a call is one async H2D copy, the kernel and one async
 // D2H copy on that stream followed by a single hipStreamSynchronize (no default-stream launch, no pageable copies, no
@@ -899,10 +917,12 @@ static void noc_host(int full_cov, double *pts2d, double *pts3d, double *wgt2d, 
     memcpy(q, clips, sizeof(double) * 5);
     if (hipMemcpyAsync(d, h, nin * sizeof(double), hipMemcpyHostToDevice, sg->st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
     NocArgs a;
+    memset(&a, 0, sizeof a);
     a.pts2d = d; a.pts3d = d + 2 * n; a.wgt2d = d + 5 * n; a.logdim = d + (5 + ws) * n; a.logdim_wgt = a.logdim + 3; a.K = a.logdim + 6;
-    a.init = a.logdim + 15; a.clips = a.logdim + 22; a.out_dimpose = d + nin; a.out_val = (int *)(d + nin + 7);
+    a.init = a.logdim + 15; a.clips = a.logdim + 22; a.out_dimpose = d + nin; a.out_val = (int *)(d + nin + 7); a.out_diag = nullptr;
+    a.K_batch = 1; a.clips_batch = 1; a.B = 1;
     a.delta = delta; a.pn = pn; a.full_cov = full_cov;
-    hipLaunchKernelGGL(pnp_noc_kernel, dim3(1), dim3(256), sizeof(double) * 2 * 4 * kRedN, sg->st, a);
+    hipLaunchKernelGGL(pnp_noc_kernel, dim3(1), dim3(256), kNocLds, sg->st, a);
     if (hipGetLastError() != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return; }
     double *ho = h + nin;
     if (hipMemcpyAsync(ho, d + nin, nout * sizeof(double), hipMemcpyDeviceToHost, sg->st) != hipSuccess ||
