@@ -191,3 +191,37 @@ def test_pose_stage_dump_hook_on_a_stand_in_roi_head(tmp_path):
     assert z['dim'].shape == (n, 3) and z['dim_var'].shape == (n, 3) and z['bboxes'].shape == (n, 4) and z['scores'].shape == (n,)
     assert z['scores_ref'].shape == (n,) and np.all((z['scores_ref'] >= 0) & (z['scores_ref'] <= 1)) and z['img_shape'].tolist() == [375.0, 1242.0]
     assert np.array_equal(z['rois'], z['bboxes']) and z['cam_intrinsic'].shape == (3, 3) and not bool(z['flip'])
+
+
+def test_integration_md_cffi_block_is_the_generated_prototype_text_and_every_symbol_is_exported():
+    """INTEGRATION.md §3 shows the text a maintainer feeds to cffi's `ffi.cdef`.  cffi is absent here, so instead of executing it
+    the test checks (a) the block is exactly what tools/gen_cffi_cdef.py derives from include/monorun_pnp.h, (b) it contains only
+    what cffi's declaration parser accepts (prototypes over plain C / stdint types and plain-integer #defines: no comments, no
+    `extern "C"`, no parenthesised or shifted macro values), (c) every prototype names a symbol the built library exports, with
+    the argument count the header declares."""
+    import ctypes
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_cffi_cdef as gen
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = md.split('<!-- cffi-cdef:begin -->')[1].split('<!-- cffi-cdef:end -->')[0]
+    text = block.split('```c\n')[1].split('```')[0]
+    assert text == gen.cdef_text(), 'INTEGRATION.md cffi block is stale: regenerate with tools/gen_cffi_cdef.py'
+    allowed = re.compile(r'^(#define MR_\w+ (0x[0-9A-Fa-f]+|\d+)|[A-Za-z_][\w \*]*\([\w \*,]*\);)$')
+    protos = []
+    for line in text.strip().split('\n'):
+        assert allowed.match(line), line
+        assert '/*' not in line and '//' not in line and 'extern' not in line and '<<' not in line and '(-' not in line
+        if not line.startswith('#define'):
+            m = re.match(r'^(.*?)(\w+)\((.*)\);$', line)
+            name, args = m.group(2), m.group(3)
+            for tok in re.findall(r'[A-Za-z_]\w*', m.group(1) + ' ' + re.sub(r'\b\w+(?=\s*(,|$))', '', args)):
+                assert tok in ('const', 'void', 'int', 'float', 'double', 'char', 'uint8_t', 'int8_t', 'int32_t', 'int64_t'), (name, tok)
+            protos.append((name, 0 if args.strip() == 'void' else args.count(',') + 1))
+    from monorun_amd import _lib
+    lib = ctypes.CDLL(_lib.SO)
+    hdr = {n: len(a) for n, _, a in gen.header_prototypes()}
+    assert set(n for n, _ in protos) == set(hdr) == set(_lib.EXPORTED_SYMBOLS)
+    for name, nargs in protos:
+        assert hasattr(lib, name) and hdr[name] == nargs, name

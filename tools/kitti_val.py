@@ -84,7 +84,11 @@ def main():
     ap.add_argument('--labels'); ap.add_argument('--calib'); ap.add_argument('--ids'); ap.add_argument('--dumps')
     ap.add_argument('--out', default=None, help='directory for the KITTI result files')
     ap.add_argument('--img-shape', type=int, nargs=2, default=(375, 1242))
+    ap.add_argument('--gpus', type=int, default=1, help='shard the images over this many GPUs (the script starts its own ranks)')
     a = ap.parse_args()
+    from monorun_amd import launch
+    if a.gpus > 1 and not launch.in_distributed_job():
+        return launch.spawn_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:])
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
