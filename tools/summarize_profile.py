@@ -37,11 +37,14 @@ for d in sorted(os.listdir(src)):
         counters[k] = dict(mean=float(np.mean(v)), min=float(np.min(v)), max=float(np.max(v)), launches=len(v), pass_dir=d)
 b = json.loads(bench)
 fetch_kb = counters['FETCH_SIZE']['mean']; write_kb = counters['WRITE_SIZE']['mean']
-# gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide (16 B/lane) coalesced reads -> double it;
-# the kernel's HBM reads are global_load_lds_dwordx4 (16 B/lane) streams.  WRITE_SIZE is used as reported.
+# gfx950: FETCH_SIZE tallies 128-B requests at 64 B for coalesced streaming reads -> double it.  The guide states this for
+# 16 B/lane reads; the kernel's HBM reads are one dword per lane (load_records), so the factor was calibrated for that width too:
+# profiles/r02_fetch_calibration.txt (tools/ubench/fetch_calib.hip: counter / true bytes = 0.5000 at 4 B/lane and at 16 B/lane).
+# WRITE_SIZE is used as reported.
 hbm = (2 * fetch_kb + write_kb) * 1024
 traffic = dict(tag=tag, hbm_bytes_per_launch=hbm, fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb,
-               fetch_correction='x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane reads; MI355X_MICROARCH.md §HBM)',
+               fetch_correction='x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B; MI355X_MICROARCH.md §HBM; calibrated for 4 B/lane reads in profiles/r02_fetch_calibration.txt)',
+               source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary` (tools/profile_round.sh {tag})',
                algorithmic_bytes_per_launch=b['roofline']['algorithmic_bytes_per_launch'],
                ratio_traffic_over_algorithmic=hbm / b['roofline']['algorithmic_bytes_per_launch'])
 json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
