@@ -363,6 +363,9 @@ def run(args):
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
                          'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)),
                          'kernel_ms_per_batch': per_batch_ms,
+                         'batch0_only': {'kernel_ms': per_batch_ms[0], 'frac': BYTES_PER_SOLVE * B_PER_GPU / (per_batch_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         'note': 'batch 0 (the config seed) alone — what round 1 measured (67.6 us, 0.043) before the steps rotated over '
+                                                 'distinct batches; a launch lasts as long as its slowest object, so batches differ'},
                          'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU, 'valu_issue': valu,
                          'flops': {'fp64_flop_per_launch': flops_per_launch, 'achieved_tflops': flops_ach, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
                                    'frac_of_fp64_vector_peak': flops_ach / FP64_VECTOR_PEAK_TFLOPS,
