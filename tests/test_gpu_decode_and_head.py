@@ -248,3 +248,25 @@ def test_prepared_and_graph_launch_for_the_per_image_regime(dev, orc):
             for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'dimensions_pred', 'inlier_mask'):
                 assert torch.equal(out[k], ref[k]), k
         assert int(ref['ret_val'].sum()) >= 55
+
+
+def test_decode_of_more_than_65535_objects_in_one_call(dev, orc):
+    """config 5's 65 536-object batch must decode unfused in ONE call (round 1 launched a 2-D grid and refused B > 65 535):
+    70 000 objects on a 4x4 RoI grid, checked against the numpy chain at the ends of the batch."""
+    from monorun_amd.pose_head import noc_decode
+    rng = np.random.default_rng(12)
+    B, C = 70000, 3
+    all_pred = torch.from_numpy(rng.normal(0, 1, (B, 2 * C * 5, 4, 4)).astype(np.float32)).to(dev)
+    labels = rng.integers(0, C, B); dim = rng.normal(0, 1, (B, 3)).astype(np.float32)
+    rois = np.stack([rng.uniform(0, 900, B), rng.uniform(0, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(20, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    dec = noc_decode(all_pred, t(labels), False, t(dim), None, t(rois))
+    torch.cuda.synchronize()
+    for sl in (slice(0, 64), slice(65500, 65600), slice(B - 64, B)):
+        ap = all_pred[sl].cpu().numpy()
+        n_noc, n_ls, _ = orc.slice_pred(ap, labels[sl], False)
+        d, _ = orc.dim_decode(dim[sl], None, labels[sl])
+        assert np.array_equal(dec['coords_3d'][sl].cpu().numpy(), orc.noc_decode(n_noc, d, None)[0])
+        assert np.array_equal(dec['coords_2d_istd'][sl].cpu().numpy(), orc.spec_expf(-orc.decode_logstd(n_ls, None)) / np.float32(10))
+        assert np.array_equal(dec['coords_2d'][sl].cpu().numpy(), orc.roi_grid(rois[sl], 4, 4))
