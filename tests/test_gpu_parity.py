@@ -410,3 +410,29 @@ def test_hip_kernel_against_the_reference_initialiser_restated(dev, orc):
     sm, df = s['same'] & s['ok'], ~s['same'] & s['ok']
     assert np.nanquantile(s['maha'][sm], 0.99) <= 0.05 and np.mean(s['maha'][sm] > 0.1) <= 0.01
     assert np.nanmax(s["maha"][df]) <= 5.0 and np.nanquantile(s['maha'][df], 0.5) <= 0.1
+
+
+def test_config5_full_size_on_one_gpu(dev, orc):
+    """BASELINE config 5 at its FULL size — 65 536 proposals x 56x56 correspondences, fp16 storage (2.9 GB of inputs) — in one
+    launch on one GPU (the 8-GPU run shards it 8 192 per rank; a single MI355X holds it 100 times over): 256 distinct objects
+    tiled 256x, so that (a) the first tile is compared with the oracle object by object and (b) every other tile must
+    reproduce it bit for bit (results do not depend on batch position or on what else is in flight)."""
+    nd, rep, hw = 256, 256, 56
+    b = syn.make_batch(B=nd, hw=hw, seed=4321)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    mk = lambda a: np.ascontiguousarray(a.astype(np.float16).transpose(0, 2, 1))                     # (nd, C, P) fp16, channel-planar
+    t = lambda a: torch.from_numpy(a).to(dev)
+    big = [t(mk(a)).repeat(rep, 1, 1).permute(0, 2, 1) for a in (x2d, istd, x3d)]                    # (65536, P, C) views, strides (C*P, 1, P)
+    assert big[0].shape == (nd * rep, hw * hw, 2) and big[0].stride() == (2 * hw * hw, 1, hw * hw)
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    valid, pose, cov, tr, mask, diag = pnp_uncert_device(big[0], big[1], big[2], t(np.asarray(K)), t(np.asarray(ur)), t(np.asarray(vr)), 0.5, 0.6,
+                                                         t(np.asarray(thr)).repeat(rep), True, with_diag=True)
+    torch.cuda.synchronize()
+    f32 = lambda a: np.ascontiguousarray(mk(a).astype(np.float32).transpose(0, 2, 1))
+    ref = orc.u2d_pnp(f32(x2d), f32(istd), f32(x3d), K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+    first = [v[:nd].cpu().numpy() for v in (valid, pose, cov, tr, mask, diag)]
+    _cmp((first[0].astype(bool), first[1], first[2], first[3], first[4].astype(bool), first[5]), ref, 'config 5, first tile')
+    for v in (valid, pose, cov, tr, mask):
+        tiles = v.view(rep, nd, *v.shape[1:])
+        assert bool((tiles == tiles[:1]).all()), 'a later tile differs from the first'
+    assert float(valid.float().mean()) > 0.97
