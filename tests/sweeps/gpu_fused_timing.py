@@ -1,6 +1,6 @@
 """Head output -> pose: one fused launch vs K2 + PnP (development aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import time
 import numpy as np, torch
 from monorun_amd import synthetic as syn

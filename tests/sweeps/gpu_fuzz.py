@@ -1,7 +1,7 @@
 """Adversarial inputs: the kernel must terminate, never report a NaN pose as valid, and agree with the oracle on validity
 (development aid; run under `timeout`)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn, _lib
 from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device

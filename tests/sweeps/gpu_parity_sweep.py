@@ -1,6 +1,6 @@
 """Parity sweep over many seeds (development aid): counts objects that deviate from the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn
 from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device

@@ -1,6 +1,6 @@
 """Quick GPU sanity + timing sweep (development aid; the judged numbers come from bench.py)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn, _lib
 from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device

@@ -3,7 +3,7 @@
 oracle/epnp.inc), compared AFTER the LM on config-2 batches — the table in DESIGN.md §5.  CPU only (oracle on both sides;
 the HIP kernel is bit-identical to the K0 oracle on masks: tests/test_gpu_parity.py).
 
-    python tools/k0_vs_epnp.py [--seeds 8] [--B 1024]
+    python tests/sweeps/k0_vs_epnp.py [--seeds 8] [--B 1024]
 """
 import argparse
 import os
@@ -11,8 +11,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
 
 
 def main():

@@ -3,7 +3,7 @@
 kernel does) and Householder QR of the augmented matrix [J S; D] (what Ceres' DENSE_QR does, pnp_uncert_cpu.cpp:270-274) — over
 a sweep of config-2 batches: iteration counts, exit reasons, trust-region radii and fp64 poses must coincide.  CPU only.
 
-    python tools/lm_qr_vs_chol_sweep.py [--seeds 200] [--B 1024]
+    python tests/sweeps/lm_qr_vs_chol_sweep.py [--seeds 200] [--B 1024]
 """
 import argparse
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():
@@ -25,7 +25,7 @@ def main():
     worst_pose = worst_tr = 0.0
     hist = {}
     for i in range(a.seeds):
-        # vary the conditions like tools/gpu_parity_sweep.py: outlier share, noise, layout
+        # vary the conditions like tests/sweeps/gpu_parity_sweep.py: outlier share, noise, layout
         b = syn.make_batch(B=a.B, seed=1000 + i, outlier_frac=(0.05, 0.15, 0.3)[i % 3], noise_3d=(0.01, 0.03, 0.08)[(i // 3) % 3])
         x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(v) for v in syn.pnp_boundary(b, planar=False)]
         orc.set_lm_options(qr=False)

@@ -90,6 +90,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'oracle' not in txt.replace('the CPU oracle', '').replace('against the CPU oracle', ''), os.path.join(dp, f)
+    # tools/ holds product-side utilities (profiling, timing, the KITTI harness): none may import the checker either; the
+    # sweeps that DO compare against it live under tests/sweeps/
+    import re
+    for f in os.listdir(os.path.join(ROOT, 'tools')):
+        if f.endswith(('.py', '.sh')):
+            txt = open(os.path.join(ROOT, 'tools', f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', txt, re.M), f
 
 
 def test_synthetic_generator_shapes_and_determinism():

@@ -60,7 +60,7 @@ def test_oracle_reproduces_the_committed_trajectories(orc, g7, qr):
 
 def test_qr_and_cholesky_step_solvers_agree_on_config2(orc):
     """the normal equations are a faithful stand-in for DENSE_QR on the workload: identical iteration counts, exit reasons,
-    masks; fp64 poses within 1e-10 (204 800-object version: tools/lm_qr_vs_chol_sweep.py, result in DESIGN.md §4)."""
+    masks; fp64 poses within 1e-10 (204 800-object version: tests/sweeps/lm_qr_vs_chol_sweep.py, result in DESIGN.md §4)."""
     for seed in (1234, 5):
         b = syn.make_batch(B=256, seed=seed)
         x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]

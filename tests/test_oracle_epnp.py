@@ -124,7 +124,7 @@ def test_config1_cube_with_the_reference_initialiser(orc):
 
 def k0_vs_epnp_statistics(orc, seed, B=256, num_threads=4):
     """post-LM results of the two initialisers on one config-2 batch (shared by the test below, the GPU test and
-    tools/k0_vs_epnp.py, which prints the table kept in DESIGN.md)."""
+    tests/sweeps/k0_vs_epnp.py, which prints the table kept in DESIGN.md)."""
     b = syn.make_batch(B=B, seed=seed)
     x2d, istd, x3d, Km, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
     r0 = orc.u2d_pnp(x2d, istd, x3d, Km, ur, vr, 0.5, 0.6, thr, True, num_threads=num_threads)
