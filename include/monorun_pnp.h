@@ -129,6 +129,22 @@ int mr_pnp6_refine_batched(
     uint8_t *valid, float *pose6, float *cov6, float *diag, void *stream);
 
 /*
+ * `forward_exact_hessian=True` (the reference's hessian.py:5-64 used by pnp_uncert.py:63-85): second launch after
+ * mr_pnp_uncert_batched (which may then run with MR_COV_NONE).  h[i][j] = d (J^T e)_i / d pose_j of the masked, weighted
+ * reprojection cost at `pose` (B,4) f32 [yaw,tx,ty,tz] — masks (z clip, per-axis uv clip, points outside inlier_mask) are
+ * constants, as they are for the reference's autograd — and cov = inverse(h) (LU semantics: h need not be positive definite).
+ * Inputs / strides / cameras / ranges as for mr_pnp_uncert_batched; inlier_mask (B,P) u8 or NULL (all points).
+ * valid (B) u8 is IN/OUT: objects entering with 0 get h = 0, cov = identity; an exactly singular or non-finite h clears the
+ * flag and yields cov = identity (the per-object reading of pnp_uncert.py:79-85).  hess (B,16) f32 may be NULL; cov (B,16) f32.
+ */
+int mr_pnp_exact_hessian_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const float *pose, const uint8_t *inlier_mask, int B, int P, float z_min,
+    uint8_t *valid, float *hess, float *cov, void *stream);
+
+/*
  * The reference's own per-object C entry point, same signature and semantics (ext.h:1-13,
  * pnp_uncert_cpu.cpp:245-292): HOST fp64 buffers in, host results out; runs the same LM kernel on the
  * GPU for one object (blocking).  result_cov may be NULL; on failure result_cov is left untouched.

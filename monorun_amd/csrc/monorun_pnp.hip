@@ -273,6 +273,7 @@ struct PnpArgs {
 
 #include "pnp_kernel.inc"
 #include "pnp6_kernel.inc"
+#include "hessian_kernel.inc"
 #include "pnp_noc_kernel.inc"
 constexpr size_t kNocLds = sizeof(double) * (2 * 4 * kRedN + 2 * 40);     // reduction scratch + two sets of block sums
 
@@ -615,6 +616,36 @@ int mr_pnp6_refine_batched(
         case MR_F64: return launch_pnp6<double>(a, (hipStream_t)stream);
         default: return MR_ERR_UNSUPPORTED;
     }
+}
+
+int mr_pnp_exact_hessian_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const float *pose, const uint8_t *inlier_mask, int B, int P, float z_min,
+    uint8_t *valid, float *hess, float *cov, void *stream) {
+    if (B < 0 || P < 1) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !pose || !valid || !cov)
+        return MR_ERR_BAD_ARGUMENT;
+    if ((cam_batch != 1 && cam_batch != B) || (range_batch != 1 && range_batch != B)) return MR_ERR_BAD_ARGUMENT;
+    HessArgs a;
+    memset(&a, 0, sizeof a);
+    a.x2d = x2d; a.istd = istd; a.x3d = x3d;
+    for (int i = 0; i < 3; ++i) { a.s2[i] = x2d_strides[i]; a.sw[i] = istd_strides[i]; a.s3[i] = x3d_strides[i]; }
+    a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9;
+    a.ur = u_range; a.vr = v_range; a.r_stride = (range_batch == 1) ? 0 : 2;
+    a.pose = pose; a.mask = inlier_mask; a.B = B; a.P = P; a.z_min = (double)z_min;
+    a.valid = valid; a.hess = hess; a.cov = cov;
+    hipStream_t st = (hipStream_t)stream;
+    switch (in_dtype) {
+        case MR_F32: hipLaunchKernelGGL((exact_hessian_kernel<float>), dim3(B), dim3(256), 0, st, a); break;
+        case MR_F16: hipLaunchKernelGGL((exact_hessian_kernel<__half>), dim3(B), dim3(256), 0, st, a); break;
+        case MR_F64: hipLaunchKernelGGL((exact_hessian_kernel<double>), dim3(B), dim3(256), 0, st, a); break;
+        default: return MR_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
 }
 
 static int fill_decode_args(DecodeArgs &a, const void *all_pred, int pred_dtype, const int64_t *labels, const uint8_t *flip, const float *dim,

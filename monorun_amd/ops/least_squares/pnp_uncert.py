@@ -143,14 +143,46 @@ def pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, 
     return valid, pose6, cov6, diag
 
 
+def exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, pose4, inlier_mask_u8, valid_u8, z_min=0.5,
+                         with_hessian=False):
+    """`forward_exact_hessian=True` on device tensors (hessian.py:5-64 + pnp_uncert.py:63-85 of the reference): the exact Hessian of
+    the masked cost at pose4 (B,4) f32 and its inverse.  inlier_mask_u8 (B,P) u8 | None, valid_u8 (B,) u8 = the 4-DoF solve's flags.
+    Returns (valid u8 (B,), cov f32 (B,4,4), hess f32 (B,4,4) | None)."""
+    lib = _lib.load()
+    dev = coords_2d.device
+    B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+    dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
+    prep = lambda t: t.detach() if (t.dtype == dt and t.device == dev) else t.detach().to(device=dev, dtype=dt)
+    x2d, istd, x3d = prep(coords_2d), prep(coords_2d_istd), prep(coords_3d)
+    f32 = dict(device=dev, dtype=torch.float32)
+    cam = cam_mats.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    ur = u_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    vr = v_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    valid = valid_u8.detach().to(device=dev, dtype=torch.uint8).clone().contiguous()
+    pose = pose4.detach().to(**f32).contiguous()
+    mask = inlier_mask_u8.detach().to(device=dev, dtype=torch.uint8).contiguous() if inlier_mask_u8 is not None else None
+    cov = torch.empty(B, 4, 4, **f32)
+    hess = torch.empty(B, 4, 4, **f32) if with_hessian else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_pnp_exact_hessian_batched(
+                x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt],
+                cam.data_ptr(), cam.shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                pose.data_ptr(), mask.data_ptr() if mask is not None else None, B, P, float(z_min),
+                valid.data_ptr(), hess.data_ptr() if hess is not None else None, cov.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return valid, cov, hess
+
+
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
                epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False):
     """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
 
     coords_2d / coords_2d_istd (B,P,2), coords_3d (B,P,3), cam_mats (B|1,3,3), u_range / v_range (B|1,2),
     epnp_ransac_thres (B,) or None — any device; host tensors are staged through the GPU.
-    forward_exact_hessian: only False (every shipped config, e.g. configs/kitti_car.py:123; the reference's exact Hessian no
-    longer runs on torch >= 2).
+    forward_exact_hessian=True (no shipped config, e.g. configs/kitti_car.py:123 sets False; the reference's own exact Hessian no
+    longer runs on torch >= 2): pose_cov = inverse of the exact Hessian of the masked cost (hessian.py:5-64) instead of
+    inverse(J^T J) — a second launch (exact_hessian_device); ignored together with use_6dof=True (the 6-DoF covariance is the
+    solver's J^T J).
     use_6dof=False (every shipped config): returns (ret_val (B,) bool, r_vec (B,1) yaw, t_vec (B,3), pose_cov (B,4,4) covariance of
     [yaw, t], inlier_mask (B,P) bool) on the device and in the dtype of coords_2d — the reference's tuple.
     use_6dof=True: the flag the reference declares and never reads (pnp_uncert.py:11) made real — after the 4-DoF solve (mask,
@@ -159,8 +191,6 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     requires the 6-DoF solve to be usable.  Because the flag is dead in the reference, every shipped config keeps running
     the 4-DoF path.
     """
-    if forward_exact_hessian:
-        raise NotImplementedError('forward_exact_hessian=True is not supported (unused by every reference config)')
     with torch.no_grad():
         src_dev = coords_2d.device
         if src_dev.type != 'cuda':
@@ -177,6 +207,8 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
             valid6, pose6, cov6, _ = pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, mask, pose, valid, z_min=z_min)
             return ((valid & valid6).to(device=src_dev, dtype=torch.bool), pose6[:, :3].to(device=src_dev, dtype=odt),
                     pose6[:, 3:].to(device=src_dev, dtype=odt), cov6.to(device=src_dev, dtype=odt), mask.to(device=src_dev, dtype=torch.bool))
+        if forward_exact_hessian:
+            valid, cov, _ = exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, pose, mask, valid, z_min=z_min)
         ret_val = valid.to(device=src_dev, dtype=torch.bool)
         r_vec = pose[:, :1].to(device=src_dev, dtype=odt)
         t_vec = pose[:, 1:].to(device=src_dev, dtype=odt)

@@ -12,6 +12,8 @@
   * ``pnp_from_head`` / ``pose_from_head`` — the whole post-NOC-head tail in ONE launch (K2 fused into the PnP kernel's
     load stage; the decoded maps never touch HBM), or two launches with ``fused=False``
 """
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -296,6 +298,11 @@ class UncertPropPnPOptimizer(nn.Module):
                  allowed_border=200, epnp_ransac_thres_ratio=0.2, std_scale=10):
         super().__init__()
         self.pnp = build_pnp(pnp)
+        if getattr(self.pnp, 'use_6dof', False):
+            # the reference never reads this flag (pnp_uncert.py:11): inside the head the pose stays [yaw, t] with a 4x4 covariance
+            # (calibration and score head are 4-DoF); the real 6-DoF refinement is ops.pnp_uncert(..., use_6dof=True)
+            warnings.warn('UncertPropPnPOptimizer: use_6dof is ignored inside the pose head (as in the reference)')
+            self.pnp.use_6dof = False
         self.epnp_ransac_thres_ratio = epnp_ransac_thres_ratio
         self.allowed_border = allowed_border
         self.std_scale = std_scale
@@ -353,8 +360,10 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
     """NOC-head output -> pose results dict (what monorun_roi_head.py:509-534 produces).
     fused=True: ONE launch (decode inside the PnP kernel); fused=False: K2 then the PnP kernel (two launches,
     the decoded maps are materialised) — both give bit-identical results."""
+    p = pose_head.pnp
+    if fused and (getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False)):
+        fused = False               # options the one-launch kernel does not implement: take the module path, which honours them
     if fused:
-        p = pose_head.pnp
         sd = decode_kw.get('ref_length', 1.6) * decode_kw.get('ref_focal_y', 722) * decode_kw.get('target_std', 0.15)
         ret_val, yaw, t_vec, cov, inlier_mask, dims, dims_var, cov_calib = pnp_from_head(
             all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape, std_scale=pose_head.std_scale,
@@ -410,6 +419,9 @@ class PoseFromHeadLaunch:
         mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
         P = h * w
         p = pose_head.pnp
+        if getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False):
+            raise ValueError('PoseFromHeadLaunch prepares the one-launch kernel: forward_exact_hessian / coord_istd_normalize '
+                             'need pose_from_head (module path)')
         self.out = dict(ret_val_u8=torch.empty(B, device=dev, dtype=torch.uint8), pose=torch.empty(B, 4, **f32), pose_cov_pred=torch.empty(B, 4, 4, **f32),
                         tr_radius=torch.empty(B, **f32), inlier_mask_u8=torch.empty(B, P, device=dev, dtype=torch.uint8),
                         dimensions_pred=torch.empty(B, 3, **f32), dimensions_var=torch.empty(B, 3, **f32) if dim_var is not None else None,

@@ -137,6 +137,25 @@ def torch_jacobian(K, z_min, u_range, v_range, yaw, t, pts2d, pts3d, istd, inlie
     return jac, err, H
 
 
+def exact_hessian(K, z_min, u_range, v_range, yaw, t, pts2d, pts3d, istd, inlier=None):
+    """hessian.py:5-64 for one object (closed form of what the reference gets by autograd): h (4,4) fp64."""
+    pts2d, pts3d, istd, K, u_range, v_range, t = map(_d, (pts2d, pts3d, istd, K, u_range, v_range, t))
+    H = np.zeros((4, 4))
+    inl = np.ascontiguousarray(inlier, np.uint8) if inlier is not None else None
+    lib().orc_exact_hessian(_p(K, c_dp), ctypes.c_double(z_min), _p(u_range, c_dp), _p(v_range, c_dp), ctypes.c_double(float(yaw)),
+                            _p(t, c_dp), _p(pts2d, c_dp), _p(pts3d, c_dp), _p(istd, c_dp), _p(inl, c_u8p), ctypes.c_int(pts2d.shape[0]),
+                            _p(H, c_dp))
+    return H
+
+
+def pose_cov_general(H):
+    """inverse(h) for a general (possibly indefinite) h: (ok, cov); singular -> (False, identity)."""
+    H = _d(H)
+    cov = np.zeros((4, 4))
+    ok = lib().orc_pose_cov_general(_p(H, c_dp), _p(cov, c_dp))
+    return bool(ok), cov
+
+
 def pose_cov(H):
     H = _d(H)
     cov = np.zeros((4, 4))

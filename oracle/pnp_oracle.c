@@ -594,6 +594,87 @@ void orc_torch_jacobian(const double *K /*9*/, double z_min, const double *u_ran
     if (H) memcpy(H, HH, sizeof HH);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * exact_hessian (hessian.py:5-64): h[i][j] = d/d pose_j of (J^T e)_i, which the reference obtains by torch autograd
+ * through the ANALYTIC Jacobian expressions of get_pose_jacobians (jacobian.py:48-98) and the weighted error of
+ * forward_proj (:4-45); the masks (z clip, per-axis uv clip, outliers) are constants for autograd and masked rows were
+ * ASSIGNED zero, so only unmasked rows contribute, and on those every expression is smooth.  Restated in closed form,
+ * differentiating exactly the reference's expressions (general K, including a third row that is not (0,0,1)):
+ *     nu_r = k_r[r].X + k_t[r],  z = k_r[2].X + k_t[2],  uv_r = nu_r / z,  Bv = c X + s Z,  A = -s X + c Z
+ *     J_r,i = w_r a_i / z,   a = [ m1[r,0] X + m1[r,1] Z + uv_r Bv,  K[r,0],  K[r,1],  K[r,2] - uv_r ]
+ *     D_j nu_r = [K[r,0] A - K[r,2] Bv, K[r,0], K[r,1], K[r,2]],  D_j z likewise with r = 2,  D_j uv_r = (D_j nu_r - uv_r D_j z) / z
+ *     D_j a_0 = D_j uv_r Bv + [j = yaw] (-K[r,0] Bv - K[r,2] A + uv_r A),   D_j a_3 = -D_j uv_r
+ *     h[i][j] = sum_r  e_r w_r (D_j a_i / z - a_i D_j z / z^2)  +  (w_r a_i / z) (w_r D_j uv_r),     e_r = w_r (uv_r - x2d_r)
+ * For K with third row (0,0,1) this is J^T J + sum_r e_r w_r Hess(uv_r), symmetric.  All fp64.
+ * ---------------------------------------------------------------------------------------- */
+void orc_exact_hessian(const double *K /*9*/, double z_min, const double *u_range, const double *v_range,
+                       double yaw, const double *t, const double *pts2d, const double *pts3d,
+                       const double *istd, const uint8_t *inlier /*nullable*/, int pn, double *H /*16*/) {
+    const double s = sin(yaw), c = cos(yaw);
+    double kr[9], kt[3];
+    for (int r = 0; r < 3; ++r) {
+        kr[3 * r + 0] = K[3 * r + 0] * c - K[3 * r + 2] * s;
+        kr[3 * r + 1] = K[3 * r + 1];
+        kr[3 * r + 2] = K[3 * r + 0] * s + K[3 * r + 2] * c;
+        kt[r] = K[3 * r + 0] * t[0] + K[3 * r + 1] * t[1] + K[3 * r + 2] * t[2];
+    }
+    const double m1[4] = { K[0] * (-s) + K[2] * (-c), K[0] * c + K[2] * (-s),
+                           K[3] * (-s) + K[5] * (-c), K[3] * c + K[5] * (-s) };
+    double HH[16]; memset(HH, 0, sizeof HH);
+    for (int i = 0; i < pn; ++i) {
+        if (inlier && !inlier[i]) continue;
+        const double X = pts3d[3 * i], Y = pts3d[3 * i + 1], Z = pts3d[3 * i + 2];
+        double uvz[3];
+        for (int r = 0; r < 3; ++r) uvz[r] = kr[3 * r] * X + kr[3 * r + 1] * Y + kr[3 * r + 2] * Z + kt[r];
+        const double z = uvz[2];
+        if (z < z_min) continue;                                   /* z clip masks both rows */
+        const double Bv = c * X + s * Z, A = -s * X + c * Z;
+        const double dz[4] = { K[6] * A - K[8] * Bv, K[6], K[7], K[8] };
+        const double lb[2] = { u_range[0], v_range[0] }, ub[2] = { u_range[1], v_range[1] };
+        for (int r = 0; r < 2; ++r) {
+            const double uv = uvz[r] / z;
+            if (uv < lb[r] || uv > ub[r]) continue;                /* per-axis clip masks this row */
+            const double w = istd[2 * i + r], e = w * (uv - pts2d[2 * i + r]);
+            const double dn[4] = { K[3 * r] * A - K[3 * r + 2] * Bv, K[3 * r], K[3 * r + 1], K[3 * r + 2] };
+            double du[4], a[4], Da[16];
+            for (int j = 0; j < 4; ++j) du[j] = (dn[j] - uv * dz[j]) / z;
+            a[0] = m1[2 * r] * X + m1[2 * r + 1] * Z + uv * Bv; a[1] = K[3 * r]; a[2] = K[3 * r + 1]; a[3] = K[3 * r + 2] - uv;
+            memset(Da, 0, sizeof Da);
+            for (int j = 0; j < 4; ++j) { Da[j] = du[j] * Bv; Da[12 + j] = -du[j]; }
+            Da[0] += -K[3 * r] * Bv - K[3 * r + 2] * A + uv * A;
+            for (int ii = 0; ii < 4; ++ii)
+                for (int j = 0; j < 4; ++j)
+                    HH[4 * ii + j] += e * w * (Da[4 * ii + j] / z - a[ii] * dz[j] / (z * z)) + (w * a[ii] / z) * (w * du[j]);
+        }
+    }
+    memcpy(H, HH, sizeof HH);
+}
+
+/* general 4x4 inverse (Gauss-Jordan, partial pivoting: what torch.inverse's LU does, pnp_uncert.py:77-78); 0 when a pivot is
+ * exactly zero or the result is not finite */
+int orc_inverse4(const double H[16], double inv[16]) {
+    double M[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { M[i][j] = H[4 * i + j]; M[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+        if (!(fabs(M[piv][col]) > 0.0)) return 0;
+        if (piv != col) for (int j = 0; j < 8; ++j) { const double tmp = M[col][j]; M[col][j] = M[piv][j]; M[piv][j] = tmp; }
+        const double d = 1.0 / M[col][col];
+        for (int j = 0; j < 8; ++j) M[col][j] *= d;
+        for (int r = 0; r < 4; ++r) if (r != col) { const double f = M[r][col]; for (int j = 0; j < 8; ++j) M[r][j] -= f * M[col][j]; }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { inv[4 * i + j] = M[i][4 + j]; if (!isfinite(inv[4 * i + j])) return 0; }
+    return 1;
+}
+
+/* pose_cov for forward_exact_hessian=True: inverse(h) by LU (h need not be positive definite); singular -> identity + invalid */
+int orc_pose_cov_general(const double H[16], double cov[16]) {
+    if (orc_inverse4(H, cov)) return 1;
+    for (int i = 0; i < 16; ++i) cov[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    return 0;
+}
+
 /* R6: pose_cov = inverse(h); singular -> identity + invalid (the per-object reading of pnp_uncert.py:77-85) */
 int orc_pose_cov(const double H[16], double cov[16]) {
     if (orc_spd_inverse4(H, cov)) return 1;
