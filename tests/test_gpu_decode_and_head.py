@@ -270,3 +270,49 @@ def test_decode_of_more_than_65535_objects_in_one_call(dev, orc):
         assert np.array_equal(dec['coords_3d'][sl].cpu().numpy(), orc.noc_decode(n_noc, d, None)[0])
         assert np.array_equal(dec['coords_2d_istd'][sl].cpu().numpy(), orc.spec_expf(-orc.decode_logstd(n_ls, None)) / np.float32(10))
         assert np.array_equal(dec['coords_2d'][sl].cpu().numpy(), orc.roi_grid(rois[sl], 4, 4))
+
+
+@pytest.mark.gpu
+def test_pose_head_honours_module_options_the_one_launch_kernel_lacks(dev, orc):
+    """A head built with forward_exact_hessian=True (or coord_istd_normalize=True) must not silently get the one-launch kernel's
+    J^T J covariance: pose_from_head takes the module path for it (same poses and masks, pose_cov = inverse of the exact Hessian),
+    the prepared launch refuses; use_6dof stays ignored inside the head, as in the reference (pnp_uncert.py:11)."""
+    import warnings
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head, PoseFromHeadLaunch
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    b = syn.make_batch(B=40, seed=8)
+    all_pred, dim = syn.encode_head_outputs(b, seed=8)
+    args = (t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), (syn.IMG_H, syn.IMG_W, 3))
+    cfg = dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True)
+    plain = UncertPropPnPOptimizer(pnp=dict(cfg, forward_exact_hessian=False)).to(dev)
+    exact = UncertPropPnPOptimizer(pnp=dict(cfg, forward_exact_hessian=True)).to(dev)
+    with torch.no_grad():
+        r0, r1 = pose_from_head(plain, *args), pose_from_head(exact, *args)
+        r1b = pose_from_head(exact, *args, fused=False)
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'inlier_mask', 'dimensions_pred'):
+        assert torch.equal(r0[k], r1[k]), k
+    assert torch.equal(r1['pose_cov_pred'], r1b['pose_cov_pred']) and torch.equal(r1['pose_cov_calib'], r1b['pose_cov_calib'])
+    ok = r0['ret_val'].cpu().numpy()
+    assert ok.sum() >= 36
+    d = (r1['pose_cov_pred'] - r0['pose_cov_pred']).abs().amax(dim=(1, 2)) / r0['pose_cov_pred'].abs().amax(dim=(1, 2))
+    assert float(d[torch.from_numpy(ok).to(dev)].min()) > 1e-5          # a different matrix for every object ...
+    # ... namely the inverse of the exact Hessian at the returned pose
+    from monorun_amd.pose_head import noc_decode
+    dec = noc_decode(*args[:6])
+    x2d = dec['coords_2d'].flatten(2).permute(0, 2, 1).cpu().numpy(); x3d = dec['coords_3d'].flatten(2).permute(0, 2, 1).cpu().numpy()
+    istd = dec['coords_2d_istd'].flatten(2).permute(0, 2, 1).cpu().numpy()
+    yaw, tv, mask, cov = [r1[k].cpu().numpy() for k in ('yaw_pred', 't_vec_pred', 'inlier_mask', 'pose_cov_pred')]
+    for i in np.nonzero(ok)[0][:12]:
+        H = orc.exact_hessian(b['K'][0] if np.ndim(b['K']) == 3 else b['K'], 0.5, [-200, syn.IMG_W + 200], [-200, syn.IMG_H + 200],
+                              float(yaw[i, 0]), tv[i], x2d[i], x3d[i], istd[i], mask[i])
+        good, co = orc.pose_cov_general(H)
+        assert good and np.abs(cov[i] - co).max() <= 1e-4 * np.abs(co).max(), i
+    with pytest.raises(ValueError, match='forward_exact_hessian'):
+        PoseFromHeadLaunch(exact, *args)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        six = UncertPropPnPOptimizer(pnp=dict(cfg, use_6dof=True)).to(dev)
+    assert any('use_6dof' in str(x.message) for x in w) and six.pnp.use_6dof is False
+    with torch.no_grad():
+        r6 = pose_from_head(six, *args)
+    assert torch.equal(r6['pose_cov_pred'], r0['pose_cov_pred'])
