@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""AP-level comparison of the two initialisers (CPU only; VERDICT r1 "missing" #2/#3, as far as it can be taken without KITTI).
+
+The same synthetic KITTI-format split that tools/kitti_val.py --synthetic evaluates on the GPU (label / calib files + raw
+head-output dumps) is run through the numpy/C restatement of the whole post-NOC-head tail twice:
+  K0   — this repo's consensus initialiser (what the HIP kernel runs; masks bit-identical to the kernel's),
+  EPnP — the reference's initialiser restated (cv2.solvePnPRansac(EPNP, 30 iterations), oracle/epnp.inc),
+each followed by the same LM; the 3-D boxes go through the same formatting and the KITTI protocol (the CPU evaluator that is
+pinned to the reference's eval.py by fixture G6).  Printed: AP (R40 and R11) per class / metric / difficulty for both, and the
+differences — BASELINE's secondary bar is |dAP3D| <= 0.1.
+
+    python tests/sweeps/ap_k0_vs_epnp.py [--images 400] [--noise 0.03 0.08] [--threads 16]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from monorun_amd import evaluation as ev, synthetic as syn                      # noqa: E402  (host-side formatting only)
+from monorun_amd.consumers import get_bbox_3d_result                             # noqa: E402
+from oracle import oracle as orc, kitti_eval as ke                               # noqa: E402
+
+CLASSES = ('Car', 'Pedestrian', 'Cyclist')
+
+
+def _kitti_val():
+    spec = importlib.util.spec_from_file_location('kitti_val', os.path.join(ROOT, 'tools', 'kitti_val.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def run_split(paths, init_mode, threads, img_shape=(375, 1242)):
+    ids = [l.strip() for l in open(paths['ids']) if l.strip()]
+    infos, results, stats = [], [], dict(valid=0, n=0)
+    for iid in ids:
+        calib = ev.open_calib_file(os.path.join(paths['calib'], iid + '.txt'), 2)
+        infos.append(ev.parse_ann_info(ev.open_label_file(os.path.join(paths['labels'], iid + '.txt')), calib, CLASSES))
+        d = np.load(os.path.join(paths['dumps'], iid + '.npz'))
+        labels, n = d['labels'], len(d['labels'])
+        noc, ls, _ = orc.slice_pred(d['all_pred'], labels, np.zeros(n, bool))
+        dims, dims_var = orc.dim_decode(d['dim'], None, labels)
+        c3d, c3v = orc.noc_decode(noc, dims, dims_var)
+        ls_px = orc.decode_logstd(ls, c3v, exp=orc.spec_expf, log=orc.spec_logf)
+        x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(orc.roi_grid(d['rois']), ls_px, c3d, img_shape, exp=orc.spec_expf)
+        ret, yaw, t, cov, _, mask = orc.u2d_pnp(x2d, istd, x3d, infos[-1]['cam_intrinsic'][None], ur, vr, 0.5, 0.6, thr, True,
+                                                init_mode=init_mode, num_threads=threads)
+        stats['valid'] += int(ret.sum()); stats['n'] += n
+        scores = d['scores'] * ret
+        import torch
+        b3 = get_bbox_3d_result(torch.from_numpy(dims), torch.from_numpy(yaw), torch.from_numpy(t), torch.from_numpy(scores.astype(np.float32)),
+                                torch.from_numpy(labels.astype(np.int64)), len(CLASSES), to_np=True)
+        b2 = np.concatenate([d['bboxes'].astype(np.float32).reshape(n, 4), d['scores'].astype(np.float32).reshape(n, 1)], 1)
+        results.append(dict(bbox_results=[b2[labels == c] for c in range(len(CLASSES))], bbox_3d_results=b3, _pose=(ret, yaw, t, mask)))
+    dts = ev.format_results(results, infos, CLASSES)
+    gts = [ev.format_gt_anno(i, CLASSES) for i in infos]
+    return {crit: ke.kitti_ap(gts, dts, CLASSES, crit) for crit in ('R40', 'R11')}, stats, results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--images', type=int, default=400)
+    ap.add_argument('--objs', type=int, default=6)
+    ap.add_argument('--threads', type=int, default=min(16, orc.max_threads()))
+    a = ap.parse_args()
+    kv = _kitti_val()
+    tmp = tempfile.mkdtemp(prefix='mr_ap_')
+    paths = kv.write_synthetic_split(tmp, a.images, objs_per_img=a.objs)
+    out = {}
+    for name, mode in (('K0', 0), ('EPnP', 1)):
+        out[name] = run_split(paths, mode, a.threads)
+        print(f'{name}: valid {out[name][1]["valid"]} / {out[name][1]["n"]}')
+    same = agree = 0
+    for r0, r1 in zip(out['K0'][2], out['EPnP'][2]):
+        m0, m1 = r0['_pose'][3], r1['_pose'][3]
+        same += int((m0 == m1).all(1).sum()); agree += len(m0)
+    print(f'identical final inlier sets: {same} / {agree} objects')
+    worst, where = 0.0, ''
+    for crit in ('R40', 'R11'):
+        a0, a1 = out['K0'][0][crit], out['EPnP'][0][crit]
+        print(f'--- {crit}: AP with K0 / with EPnP+RANSAC / difference   (easy, moderate, hard)')
+        for key in ('bbox', 'aos', 'bev', '3d'):
+            if key not in a0:
+                continue
+            v0, v1 = np.asarray(a0[key], float), np.asarray(a1[key], float)       # (class, difficulty, strict | loose overlap)
+            for ci, cname in enumerate(CLASSES):
+                for oi, oname in enumerate(('strict', 'loose')):
+                    f = lambda v: ' '.join(f'{x:7.3f}' for x in v[ci, :, oi])
+                    d = ' '.join(f'{x:+7.3f}' for x in (v0 - v1)[ci, :, oi])
+                    print(f'{key:5s} {cname:10s} {oname:6s} {f(v0)}  |  {f(v1)}  |  {d}')
+                    w = float(np.abs((v0 - v1)[ci, :, oi]).max())
+                    if w > worst:
+                        worst, where = w, f'{crit} {key} {cname} {oname}'
+    print(f'largest |dAP| over all classes / metrics / difficulties / criteria: {worst:.3f} ({where})')
+
+
+if __name__ == '__main__':
+    main()
