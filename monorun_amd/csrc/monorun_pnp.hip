@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) nms_bev_kernel(const float *boxes, const 
 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
     size_t n = 0;
-    n += sizeof(double) * (2 * wpo * kRedN + 8);          // reduction scratch + leader/follower message
+    n += sizeof(double) * (2 * wpo * kRedN + kMsg);       // reduction scratch + leader/follower message + camera matrix
     n += sizeof(unsigned long long) * a.nca;
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
