@@ -142,3 +142,29 @@ def test_forward_exact_hessian_flag_end_to_end(dev, orc, batch64):
         assert ok
         worst = max(worst, _rel(cov[b].astype(np.float64), co))
     assert worst <= 1e-4, worst
+
+
+@pytest.mark.gpu
+def test_exact_hessian_edge_inputs(dev, orc, batch64):
+    """Empty batch, fp16 storage, non-planar (B,P,C) layout and a C-ABI argument check."""
+    from monorun_amd import synthetic as syn, _lib
+    from monorun_amd.ops import pnp_uncert
+    from monorun_amd.ops.least_squares.pnp_uncert import exact_hessian_device
+    e = pnp_uncert(torch.zeros(0, 784, 2, device=dev), torch.zeros(0, 784, 2, device=dev), torch.zeros(0, 784, 3, device=dev),
+                   torch.eye(3, device=dev)[None], torch.zeros(1, 2, device=dev), torch.zeros(1, 2, device=dev), forward_exact_hessian=True)
+    assert [tuple(t.shape) for t in e] == [(0,), (0, 1), (0, 3), (0, 4, 4), (0, 784)] and e[0].dtype == torch.bool
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=False)
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+    base = pnp_uncert(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=t(thr), inlier_opt_only=True)
+    pose = torch.cat([base[1], base[2]], 1)
+    v32, c32, h32 = exact_hessian_device(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), pose, base[4].to(torch.uint8), base[0].to(torch.uint8), with_hessian=True)
+    # fp16 storage: the kernel widens exactly, so it must equal the fp32 run on the fp16-rounded values
+    h16 = lambda a: t(a, torch.float16)
+    v16, c16, hh16 = exact_hessian_device(h16(x2d), h16(istd), h16(x3d), t(K), t(ur), t(vr), pose, base[4].to(torch.uint8), base[0].to(torch.uint8), with_hessian=True)
+    v16b, c16b, hh16b = exact_hessian_device(h16(x2d).float(), h16(istd).float(), h16(x3d).float(), t(K), t(ur), t(vr), pose, base[4].to(torch.uint8),
+                                            base[0].to(torch.uint8), with_hessian=True)
+    assert torch.equal(hh16, hh16b) and torch.equal(c16, c16b) and torch.equal(v16, v16b)
+    assert torch.equal(v32, base[0].to(torch.uint8))                 # no object of this batch has a singular exact Hessian
+    lib = _lib.load()
+    assert lib.mr_pnp_exact_hessian_batched(None, None, None, None, None, None, 0, None, 1, None, None, 1, None, None, 4, 16, 0.5, None, None, None, None) == -1
+    assert lib.mr_pnp_exact_hessian_batched(None, None, None, None, None, None, 0, None, 1, None, None, 1, None, None, 0, 16, 0.5, None, None, None, None) == 0
