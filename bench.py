@@ -132,7 +132,30 @@ def main():
     run(args)
 
 
+_JSON_FD = None
+
+
+def _protect_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL's version banner, ROCm warnings), and their
+    C-level buffers are flushed at exit, i.e. after the line: everything written to fd 1 from here on goes to stderr, and the line
+    itself is written to the saved descriptor."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    data = (json.dumps(line) + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def run(args):
+    _protect_stdout()
     global B_PER_GPU, HW, P, SEED, BYTES_PER_SOLVE
     import torch
     import torch.distributed as dist
@@ -177,9 +200,14 @@ def run(args):
         d.copy_(t)
         return d
 
-    # ---- synthetic batches for this rank, resident in HBM.  Batch 0 of rank 0 is the config's own seed.
+    # ---- synthetic batches, resident in HBM.  Batch 0 is the config's own seed.  Every rank holds the SAME NB batches and walks them
+    #      with a rank-dependent offset: at any step the ranks solve different batches (weak scaling: N x 1024 distinct objects per
+    #      step while NB >= N), but over a full rotation every rank does the same work — a launch lasts as long as its slowest object
+    #      (56 - 98 us between batches), and with per-rank seeds the N-GPU figure would measure which rank drew the slowest batches,
+    #      not how the system scales.
     NB = max(1, args.batches)
-    seeds = [SEED + 7919 * i + 104729 * rank for i in range(NB)]
+    seeds = [SEED + 7919 * i for i in range(NB)]
+    rot0 = (rank * NB) // max(world, 1)                      # this rank's starting offset into the rotation
     dev_batches, np_batch0, batch0 = [], None, None
     for i, sd in enumerate(seeds):
         if stress:                               # 1024 distinct objects, tiled 8x (generation time), stored as fp16 channel-planar
@@ -198,15 +226,18 @@ def run(args):
             np_batch0, batch0 = [np.asarray(a) for a in np_inputs], batch
     resident_bytes = sum(sum(t.numel() * t.element_size() for t in b[:3]) for b in dev_batches)
 
-    # two result buffers: with N > 1 the all-gather of step i overlaps the kernel of step i+1
-    packs = [PackedResults(B_PER_GPU, dev) for _ in range(2)]
-    masks = [torch.empty(B_PER_GPU, P, device=dev, dtype=torch.uint8) for _ in range(2)]
+    # a ring of result buffers: with N > 1 the all-gather of step i overlaps the kernels of the following steps, and a rank may run up
+    # to RING - 1 steps ahead of the slowest one (the collective couples the ranks; the per-batch spread of the launch time is
+    # absorbed by the ring instead of stalling every rank on every step's slowest launch)
+    RING = max(2, int(os.environ.get('MR_BENCH_RING', '4'))) if use_dist else 1
+    packs = [PackedResults(B_PER_GPU, dev) for _ in range(RING)]
+    masks = [torch.empty(B_PER_GPU, P, device=dev, dtype=torch.uint8) for _ in range(RING)]
 
     def mk(bi, k, **kw):
         x2d, istd, x3d, K, ur, vr, thr = dev_batches[bi]
         return PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr, inlier_opt_only=True,
                          flags=(args.waves << 8), out=packs[k] if k is not None else None, mask=masks[k] if k is not None else None, **kw)
-    launches = [[mk(bi, k) for k in range(2 if use_dist else 1)] for bi in range(NB)]
+    launches = [[mk(bi, k) for k in range(RING)] for bi in range(NB)]
     gathered = [torch.empty(world * pk.buf.numel(), dtype=torch.uint8, device=dev) for pk in packs] if use_dist else None
     # exchange: a private RCCL communicator driven directly (ncclAllGather on a side stream, ~5 us of host time per call);
     # MR_BENCH_COMM=torch, or any failure to set it up, falls back to torch.distributed's (synchronous) all-gather
@@ -227,18 +258,18 @@ def run(args):
         comm = {'backend': 'rccl (private communicator, ncclAllGather on a side stream, overlapped with the next step)' if rccl is not None
                 else 'rccl via torch.distributed (nccl backend) all_gather_into_tensor',
                 'nranks': rccl.nranks() if rccl is not None else dist.get_world_size(),
-                'bytes_per_rank': packs[0].buf.numel(), 'collectives_per_step': 1}
-    done = [None, None]
+                'bytes_per_rank': packs[0].buf.numel(), 'collectives_per_step': 1, 'result_ring': RING}
+    done = [None] * RING
     counter = [0]
 
     def step():
         i = counter[0]
         counter[0] += 1
-        bi = i % NB
+        bi = (i + rot0) % NB
         if not use_dist:
             launches[bi][0].run()
             return
-        k = i & 1
+        k = i % RING
         if oversub:
             launches[bi][k].run()
             host_send.copy_(packs[k].buf, non_blocking=True)
@@ -257,7 +288,7 @@ def run(args):
 
     def fence():
         if use_dist:
-            for k in range(2):
+            for k in range(RING):
                 if done[k] is not None:
                     torch.cuda.current_stream().wait_event(done[k])
                     done[k] = None
@@ -280,7 +311,7 @@ def run(args):
     gather_ok = None
     if use_dist:                                 # the gathered buffer holds every rank's rows (rank-major): check this rank's slice
         torch.cuda.synchronize()
-        k = (counter[0] - 1) & 1
+        k = (counter[0] - 1) % RING
         n = packs[k].buf.numel()
         gather_ok = bool(torch.equal(gathered[k][rank * n:(rank + 1) * n], packs[k].buf))
 
@@ -356,7 +387,8 @@ def run(args):
                        'objects_per_gpu': B_PER_GPU, 'points_per_object': P, 'seed': SEED,
                        'resident_batches': NB, 'resident_input_bytes': resident_bytes,
                        'batch_rotation': f'steps rotate over {NB} distinct batches (seeds {seeds[0]}, {seeds[0]}+7919*i); {resident_bytes / 2**20:.0f} MiB of inputs '
-                                         'resident, more than the 256 MiB Infinity Cache',
+                                         'resident, more than the 256 MiB Infinity Cache' + (f'; every rank holds the same {NB} batches and starts '
+                                         f'the rotation at offset rank*{NB}//{world} (distinct batches across ranks at every step, equal work per rotation)' if world > 1 else ''),
                        'stages': 'istd mask + K0 consensus initialiser (32 hyp.) + LM (Ceres-1.14 semantics, fp64) + covariance',
                        'parallelism': f'objects sharded x{world}' + (', 1 all-gather of 88 B/object per step' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -389,7 +421,7 @@ def run(args):
                 line['speedup_vs_cpu_epnp_1thread'] = line['value'] / cb['cpu_baseline_epnp']['value']
             if 'init_given' in extra:
                 line['speedup_init_given_vs_cpu_1thread'] = extra['init_given']['value'] / cb['cpu_baseline_init_given']['value']
-        print(json.dumps(line))
+        _emit(line)
     if rccl is not None:
         rccl.close()
     if use_dist:
