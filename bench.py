@@ -226,39 +226,48 @@ def run(args):
             np_batch0, batch0 = [np.asarray(a) for a in np_inputs], batch
     resident_bytes = sum(sum(t.numel() * t.element_size() for t in b[:3]) for b in dev_batches)
 
-    # a ring of result buffers: with N > 1 the all-gather of step i overlaps the kernels of the following steps, and a rank may run up
-    # to RING - 1 steps ahead of the slowest one (the collective couples the ranks; the per-batch spread of the launch time is
-    # absorbed by the ring instead of stalling every rank on every step's slowest launch)
+    # exchange: a private RCCL communicator driven directly (ncclAllGather on a high-priority side stream, ~5 us of host time per
+    # call); MR_BENCH_COMM=torch, or any failure to set it up, falls back to torch.distributed's (synchronous) all-gather
+    rccl = None
+    if use_dist and not oversub and os.environ.get('MR_BENCH_COMM', 'rccl') == 'rccl':
+        try:
+            from monorun_amd.parallel import RcclAllGather
+            rccl = RcclAllGather(dev)
+        except Exception as e:                                   # noqa: BLE001 — any setup problem: use the c10d path
+            print(f'[bench] direct RCCL path unavailable ({e}); using torch.distributed', file=sys.stderr)
+            rccl = None
+    # Result buffers: a ring of RING groups of G slots.  One step fills one slot (the kernel writes straight into it); a group —
+    # G consecutive steps' results, one contiguous buffer — is exchanged with ONE all-gather ("fewer, larger collectives": the
+    # message is latency-bound either way, 88 KiB per step and rank), on the side stream, while the following steps compute.
+    # Why groups: every command on the side queue and every cross-stream dependency costs the COMPUTE stream ~5 us on this stack
+    # (tools/rccl_step_cost.py: record 3.5, side-stream collective 5, wait or query on its event 5), so they are paid once per G
+    # steps.  Why a ring: the collective couples the ranks and a launch lasts as long as its slowest object (56 - 98 us between
+    # batches); a rank may run RING - 1 groups ahead of the slowest one instead of stalling on every step's slowest launch.
     RING = max(2, int(os.environ.get('MR_BENCH_RING', '4'))) if use_dist else 1
-    packs = [PackedResults(B_PER_GPU, dev) for _ in range(RING)]
-    masks = [torch.empty(B_PER_GPU, P, device=dev, dtype=torch.uint8) for _ in range(RING)]
+    G = max(1, int(os.environ.get('MR_BENCH_GATHER_EVERY', '8'))) if rccl is not None else 1
+    S = RING * G
+    row = B_PER_GPU * ROW_BYTES
+    gbuf = [torch.zeros(G * row, dtype=torch.uint8, device=dev) for _ in range(RING)]
+    packs = [PackedResults(B_PER_GPU, dev, buf=gbuf[sl // G][(sl % G) * row:(sl % G + 1) * row]) for sl in range(S)]
+    masks = [torch.empty(B_PER_GPU, P, device=dev, dtype=torch.uint8) for _ in range(S)]
 
     def mk(bi, k, **kw):
         x2d, istd, x3d, K, ur, vr, thr = dev_batches[bi]
         return PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr, inlier_opt_only=True,
                          flags=(args.waves << 8), out=packs[k] if k is not None else None, mask=masks[k] if k is not None else None, **kw)
-    launches = [[mk(bi, k) for k in range(RING)] for bi in range(NB)]
-    gathered = [torch.empty(world * pk.buf.numel(), dtype=torch.uint8, device=dev) for pk in packs] if use_dist else None
-    # exchange: a private RCCL communicator driven directly (ncclAllGather on a side stream, ~5 us of host time per call);
-    # MR_BENCH_COMM=torch, or any failure to set it up, falls back to torch.distributed's (synchronous) all-gather
-    rccl, comm = None, None
+    launches = [[mk(bi, k) for k in range(S)] for bi in range(NB)]
+    gathered = [torch.empty(world * b.numel(), dtype=torch.uint8, device=dev) for b in gbuf] if use_dist else None
+    comm = None
     if use_dist and oversub:
         comm = {'backend': 'gloo (host-staged; MR_BENCH_OVERSUBSCRIBE test mode: several ranks share one GPU, which RCCL refuses)',
-                'nranks': dist.get_world_size(), 'bytes_per_rank': packs[0].buf.numel()}
-        host_send = torch.empty(packs[0].buf.numel(), dtype=torch.uint8).pin_memory()
-        host_recv = torch.empty(world * packs[0].buf.numel(), dtype=torch.uint8).pin_memory()
+                'nranks': dist.get_world_size(), 'bytes_per_rank': row}
+        host_send = torch.empty(row, dtype=torch.uint8).pin_memory()
+        host_recv = torch.empty(world * row, dtype=torch.uint8).pin_memory()
     elif use_dist:
-        if os.environ.get('MR_BENCH_COMM', 'rccl') == 'rccl':
-            try:
-                from monorun_amd.parallel import RcclAllGather
-                rccl = RcclAllGather(dev)
-            except Exception as e:                                   # noqa: BLE001 — any setup problem: use the c10d path
-                print(f'[bench] direct RCCL path unavailable ({e}); using torch.distributed', file=sys.stderr)
-                rccl = None
-        comm = {'backend': 'rccl (private communicator, ncclAllGather on a side stream, overlapped with the next step)' if rccl is not None
+        comm = {'backend': 'rccl (private communicator, ncclAllGather on a side stream, overlapped with the following steps)' if rccl is not None
                 else 'rccl via torch.distributed (nccl backend) all_gather_into_tensor',
                 'nranks': rccl.nranks() if rccl is not None else dist.get_world_size(),
-                'bytes_per_rank': packs[0].buf.numel(), 'collectives_per_step': 1, 'result_ring': RING}
+                'bytes_per_rank': G * row, 'steps_per_collective': G, 'result_ring_groups': RING}
     done = [None] * RING
     counter = [0]
 
@@ -269,25 +278,33 @@ def run(args):
         if not use_dist:
             launches[bi][0].run()
             return
-        k = i % RING
+        sl = i % S
+        g, j = sl // G, sl % G
         if oversub:
-            launches[bi][k].run()
-            host_send.copy_(packs[k].buf, non_blocking=True)
+            launches[bi][sl].run()
+            host_send.copy_(packs[sl].buf, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             dist.all_gather_into_tensor(host_recv, host_send)
-            gathered[k].copy_(host_recv, non_blocking=True)
+            gathered[g].copy_(host_recv, non_blocking=True)
             return
         if rccl is None:
-            launches[bi][k].run()
-            dist.all_gather_into_tensor(gathered[k], packs[k].buf)
+            launches[bi][sl].run()
+            dist.all_gather_into_tensor(gathered[g], gbuf[g])
             return
-        if done[k] is not None:
-            torch.cuda.current_stream().wait_event(done[k])     # the gather that read buffer k finished before it is rewritten
-        launches[bi][k].run()
-        done[k] = rccl.gather(packs[k].buf, gathered[k])
+        if j == 0 and done[g] is not None:
+            # group g is about to be rewritten: its previous exchange (RING groups ago) must have finished; normally it has, long ago
+            if not done[g].query():
+                torch.cuda.current_stream().wait_event(done[g])
+            done[g] = None
+        launches[bi][sl].run()
+        if j == G - 1:
+            done[g] = rccl.gather(gbuf[g], gathered[g])
 
     def fence():
         if use_dist:
+            if rccl is not None and counter[0] % G != 0:           # a group that is only partly filled: exchange it as it is
+                g = ((counter[0] - 1) % S) // G
+                done[g] = rccl.gather(gbuf[g], gathered[g])
             for k in range(RING):
                 if done[k] is not None:
                     torch.cuda.current_stream().wait_event(done[k])
@@ -311,9 +328,9 @@ def run(args):
     gather_ok = None
     if use_dist:                                 # the gathered buffer holds every rank's rows (rank-major): check this rank's slice
         torch.cuda.synchronize()
-        k = (counter[0] - 1) % RING
-        n = packs[k].buf.numel()
-        gather_ok = bool(torch.equal(gathered[k][rank * n:(rank + 1) * n], packs[k].buf))
+        g = ((counter[0] - 1) % S) // G
+        n = gbuf[g].numel()
+        gather_ok = bool(torch.equal(gathered[g][rank * n:(rank + 1) * n], gbuf[g]))
 
     # dominant-kernel duration: HIP events around each launch on the launch stream (torch's current stream), rotating batches
     n_ev = min(max(args.steps, NB), 240)
