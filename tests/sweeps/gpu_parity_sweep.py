@@ -1,4 +1,7 @@
-"""Parity sweep over many seeds (development aid): counts objects that deviate from the oracle."""
+"""Parity sweep over many seeds: counts objects that deviate from the oracle.
+    NSEEDS=200 python tests/sweeps/gpu_parity_sweep.py                    # config-2 shape: 1024 objects x 28x28 per seed
+    HW=56 B=512 NSEEDS=16 python tests/sweeps/gpu_parity_sweep.py         # config-5 shape (3136 points: multi-trip loops, 66 KB tiles); odd seeds store fp16
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -8,16 +11,22 @@ from oracle import oracle as orc
 dev = torch.device('cuda:0')
 def dv(a):
     t = torch.from_numpy(np.asarray(a)); d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev); d.copy_(t); return d
-nseeds = int(os.environ.get('NSEEDS', 24)); B = 1024
+nseeds = int(os.environ.get('NSEEDS', 24)); B = int(os.environ.get('B', 1024)); HW = int(os.environ.get('HW', 28))
 tot = dict(objects=0, mask=0, iters=0, why=0, valid=0, pose=0, cov=0)
 worst_pose = 0.0; worst_cov = 0.0
 nthr = 16
 for seed in range(100, 100 + nseeds):
     planar = seed % 2 == 0
-    b = syn.make_batch(B=B, seed=seed, outlier_frac=[0.15, 0.3, 0.05][seed % 3], noise_3d=[0.03, 0.08][seed % 2])
+    b = syn.make_batch(B=B, hw=HW, seed=seed, outlier_frac=[0.15, 0.3, 0.05][seed % 3], noise_3d=[0.03, 0.08][seed % 2])
     x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=planar)
+    half = HW != 28 and (seed // 2) % 2 == 1          # config-5 shape: every other pair of seeds in fp16 storage (the oracle sees the rounded values)
+    if half:
+        keep = lambda a: np.ascontiguousarray(a.astype(np.float16).astype(np.float32).transpose(0, 2, 1)).transpose(0, 2, 1) if planar else \
+            np.ascontiguousarray(a.astype(np.float16).astype(np.float32))
+        x2d, istd, x3d = keep(x2d), keep(istd), keep(x3d)
     ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=nthr)
-    out = pnp_uncert_device(dv(x2d), dv(istd), dv(x3d), dv(K), dv(ur), dv(vr), 0.5, 0.6, dv(thr), True, with_diag=True)
+    h = (lambda t: t.to(torch.float16)) if half else (lambda t: t)
+    out = pnp_uncert_device(h(dv(x2d)), h(dv(istd)), h(dv(x3d)), dv(K), dv(ur), dv(vr), 0.5, 0.6, dv(thr), True, with_diag=True)
     torch.cuda.synchronize()
     valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out]
     mm = (mask.astype(bool) != ref[5]).any(1)
@@ -29,5 +38,5 @@ for seed in range(100, 100 + nseeds):
     tot['objects'] += B; tot['mask'] += mm.sum(); tot['iters'] += it.sum(); tot['why'] += wy.sum(); tot['valid'] += vv.sum()
     tot['pose'] += (dp[ok] > 1e-4).sum(); tot['cov'] += (dc[ok] > 1e-5).sum()
     worst_pose = max(worst_pose, dp[ok].max()); worst_cov = max(worst_cov, dc[ok].max())
-    print(f'seed {seed} planar={planar}: valid {ref[0].mean():.3f} mask-mismatch objs {mm.sum()} iter-mismatch {it.sum()} max|dpose| {dp[ok].max():.2e} max rel dcov {dc[ok].max():.2e} iters max {int(ref[6][:,0].max())}')
+    print(f'seed {seed} planar={planar} fp16={half}: valid {ref[0].mean():.3f} mask-mismatch objs {mm.sum()} iter-mismatch {it.sum()} max|dpose| {dp[ok].max():.2e} max rel dcov {dc[ok].max():.2e} iters max {int(ref[6][:,0].max())}')
 print('TOTAL', tot, 'worst pose', worst_pose, 'worst cov', worst_cov)
