@@ -436,3 +436,26 @@ def test_config5_full_size_on_one_gpu(dev, orc):
         tiles = v.view(rep, nd, *v.shape[1:])
         assert bool((tiles == tiles[:1]).all()), 'a later tile differs from the first'
     assert float(valid.float().mean()) > 0.97
+
+
+@pytest.mark.gpu
+def test_half_a_million_objects_in_one_launch_64bit_offsets(dev, orc):
+    """500 000 objects x 28x28 in ONE launch: 11 GB of correspondences, the X3d tensor alone is 4.7 GB — every per-object base offset
+    beyond 2^32 bytes, grid of 500 000 workgroups.  500 distinct objects tiled 1000x: the first tile is compared with the oracle,
+    every other tile must reproduce it bit for bit."""
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    nd, rep = 500, 1000
+    b = syn.make_batch(B=nd, seed=77)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a))).to(dev)
+    planar = lambda a: t(np.ascontiguousarray(np.asarray(a).transpose(0, 2, 1))).repeat(rep, 1, 1).permute(0, 2, 1)      # (B, P, C) views of (B, C, P)
+    big = [planar(a) for a in (x2d, istd, x3d)]
+    assert big[2].numel() * 4 > 2 ** 32 and big[0].shape[0] == nd * rep
+    valid, pose, cov, tr, mask, diag = pnp_uncert_device(big[0], big[1], big[2], t(K), t(ur), t(vr), 0.5, 0.6, t(thr).repeat(rep), True, with_diag=True)
+    torch.cuda.synchronize()
+    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+    first = [v[:nd].cpu().numpy() for v in (valid, pose, cov, tr, mask, diag)]
+    _cmp((first[0].astype(bool), first[1], first[2], first[3], first[4].astype(bool), first[5]), ref, '500k objects, first tile')
+    for v in (valid, pose, cov, tr, mask):
+        tiles = v.view(rep, nd, *v.shape[1:])
+        assert bool((tiles == tiles[:1]).all()), 'a later tile differs from the first'
