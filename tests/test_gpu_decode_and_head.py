@@ -316,3 +316,26 @@ def test_pose_head_honours_module_options_the_one_launch_kernel_lacks(dev, orc):
     with torch.no_grad():
         r6 = pose_from_head(six, *args)
     assert torch.equal(r6['pose_cov_pred'], r0['pose_cov_pred'])
+
+
+@pytest.mark.gpu
+def test_fused_head_to_pose_on_70000_objects(dev):
+    """The one-launch head->pose kernel on 70 144 objects (6.6 GB of raw head output, offsets beyond 2^32 bytes): 256 distinct
+    objects tiled 274x — the first tile equals the 256-object call bit for bit, and so does every other tile."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
+    nd, rep = 256, 274
+    b = syn.make_batch(B=nd, seed=21)
+    all_pred, dim = syn.encode_head_outputs(b, seed=21)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    head = UncertPropPnPOptimizer().to(dev)
+    shape = (syn.IMG_H, syn.IMG_W, 3)
+    with torch.no_grad():
+        small = pose_from_head(head, t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), shape)
+        big = pose_from_head(head, t(all_pred).repeat(rep, 1, 1, 1), t(b['labels']).repeat(rep), False, t(dim).repeat(rep, 1), None,
+                             t(b['rois']).repeat(rep, 1), t(b['K']), shape)
+    torch.cuda.synchronize()
+    assert big['ret_val'].shape[0] == nd * rep and int(small['ret_val'].sum()) >= 250
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'dimensions_pred', 'inlier_mask'):
+        tiles = big[k].view(rep, nd, *big[k].shape[1:])
+        assert torch.equal(tiles[0], small[k]), k
+        assert bool((tiles == tiles[:1]).all()), k
