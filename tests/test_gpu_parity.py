@@ -459,3 +459,53 @@ def test_half_a_million_objects_in_one_launch_64bit_offsets(dev, orc):
     for v in (valid, pose, cov, tr, mask):
         tiles = v.view(rep, nd, *v.shape[1:])
         assert bool((tiles == tiles[:1]).all()), 'a later tile differs from the first'
+
+
+@pytest.mark.gpu
+def test_legacy_entry_point_from_many_threads(dev, orc, batch64):
+    """The reference's per-object symbol is documented as stateless and re-entrant (ext.h:1-13; SURVEY 8b "Threading"): eight host
+    threads call `pnp_uncert` concurrently (ctypes releases the GIL; the library serialises on its staging buffers) on different
+    objects — every result equals the serial one bit for bit, while batched launches run on another stream in between."""
+    import threading
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device
+    lib = _lib.load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(batch64, planar=False)
+    clips = np.array([0.5, -200, 1442, -200, 575.0])
+    jobs = []
+    for o in range(32):
+        sel = ~batch64['outlier'][o].ravel()
+        init = np.array([batch64['gt_yaw'][o], *batch64['gt_t'][o]]) + np.array([0.1, 0.2, 0.1, 1.0])
+        jobs.append([np.ascontiguousarray(a, np.float64) for a in (x2d[o][sel], x3d[o][sel], istd[o][sel], K[0], init, clips)])
+
+    def call(j):
+        p2, p3, w, Kd, init, cl = j
+        val = np.zeros(1, np.int32); pose = np.zeros(4); cov = np.eye(4); tr = np.zeros(1)
+        lib.pnp_uncert(p2.ctypes.data_as(dp), p3.ctypes.data_as(dp), w.ctypes.data_as(dp), Kd.ctypes.data_as(dp), init.ctypes.data_as(dp),
+                       val.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), pose.ctypes.data_as(dp), cov.ctypes.data_as(dp), tr.ctypes.data_as(dp),
+                       p2.shape[0], cl.ctypes.data_as(dp))
+        return int(val[0]), pose, cov, float(tr[0])
+    serial = [call(j) for j in jobs]
+    out = [None] * len(jobs)
+
+    def worker(k):
+        for rep in range(3):
+            for i in range(k, len(jobs), 8):
+                out[i] = call(jobs[i])
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    args = [t(a) for a in (x2d, istd, x3d, K, ur, vr)]
+    side = torch.cuda.Stream(device=dev)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for x in th:
+        x.start()
+    with torch.cuda.stream(side):
+        batched = [pnp_uncert_device(*args, 0.5, 0.6, t(thr), True) for _ in range(20)]
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    for (v0, p0, c0, t0), (v1, p1, c1, t1) in zip(serial, out):
+        assert v0 == v1 == 1 and np.array_equal(p0, p1) and np.array_equal(c0, c1) and t0 == t1
+    for b in batched[1:]:
+        assert torch.equal(b[1], batched[0][1]) and torch.equal(b[4], batched[0][4])
+    assert int(batched[0][0].sum()) >= 60
