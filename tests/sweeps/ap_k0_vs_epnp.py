@@ -67,10 +67,13 @@ def main():
     ap.add_argument('--images', type=int, default=400)
     ap.add_argument('--objs', type=int, default=6)
     ap.add_argument('--threads', type=int, default=min(16, orc.max_threads()))
+    ap.add_argument('--outliers', type=float, default=0.1, help='share of gross outliers among the correspondences')
+    ap.add_argument('--noise', type=float, default=0.03, help='3-D noise of the inlier correspondences (m)')
     a = ap.parse_args()
     kv = _kitti_val()
     tmp = tempfile.mkdtemp(prefix='mr_ap_')
-    paths = kv.write_synthetic_split(tmp, a.images, objs_per_img=a.objs)
+    paths = kv.write_synthetic_split(tmp, a.images, objs_per_img=a.objs, outlier_frac=a.outliers, noise_3d=a.noise)
+    print(f'{a.images} images x {a.objs} objects, outlier share {a.outliers}, 3-D noise {a.noise} m')
     out = {}
     for name, mode in (('K0', 0), ('EPnP', 1)):
         out[name] = run_split(paths, mode, a.threads)

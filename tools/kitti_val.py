@@ -26,10 +26,10 @@ from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head        
 CLASSES = ('Car', 'Pedestrian', 'Cyclist')
 
 
-def write_synthetic_split(root, n_img, seed=0, objs_per_img=6):
+def write_synthetic_split(root, n_img, seed=0, objs_per_img=6, outlier_frac=0.1, noise_3d=0.03):
     """Synthetic 'dataset': KITTI label + calib files and head-output dumps for n_img images."""
     os.makedirs(os.path.join(root, 'label_2')); os.makedirs(os.path.join(root, 'calib')); os.makedirs(os.path.join(root, 'dumps'))
-    batch = syn.make_batch(B=n_img * objs_per_img, seed=seed, outlier_frac=0.1)
+    batch = syn.make_batch(B=n_img * objs_per_img, seed=seed, outlier_frac=outlier_frac, noise_3d=noise_3d)
     all_pred, dim = syn.encode_head_outputs(batch, seed=seed)
     rng = np.random.default_rng(seed)
     P2 = np.concatenate([syn.KITTI_K, np.array([[44.86], [0.2164], [0.0027]])], 1)          # KITTI-like P2 with a camera offset
