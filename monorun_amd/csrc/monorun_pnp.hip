@@ -20,10 +20,10 @@ constexpr uint32_t kK0Seed = 0x9E3779B9u;
 constexpr int kRedN = 32;           // doubles per wave in the cross-wave reduction scratch
 constexpr int kMaxDevices = 64;     // per-device library state (LDS opt-in, host-entry staging) is keyed by HIP device id
 #ifndef MR_MIN_WAVES
-#define MR_MIN_WAVES 3              // waves per SIMD the register allocator must allow: fp16 / fp64 storage (<= 168 VGPRs)
+#define MR_MIN_WAVES 3              // waves per SIMD the register allocator must allow: fp64 storage (<= 168 VGPRs)
 #endif
 #ifndef MR_MIN_WAVES_F32
-#define MR_MIN_WAVES_F32 4          // fp32 storage (the pipeline's case): <= 128 VGPRs, so that the 1024 four-wave blocks of a
+#define MR_MIN_WAVES_F32 4          // fp32 and 16-bit storage (the pipeline's cases): <= 128 VGPRs, so that the 1024 four-wave blocks of a
 #endif                              // config-2 launch are all resident (measured: 76 us vs 83 us when the allocator lands on 139 VGPRs)
 
 // ------------------------------------------------------------------------------------------------
@@ -505,6 +505,16 @@ int pick_wpo(int B, int P, int flags) {
     return w;
 }
 
+// Tiles so large that at most two workgroups fit the 160 KB of a CU (config 5: 56x56 points, 66 KB as fp16, 100 KB as fp32):
+// with 4 waves per object a CU would hold 8 waves; 8 waves per object restore 16 (4 per SIMD — the 128-VGPR kernels allow it).
+// Measured on the config-5 shard (8192 objects, fp16): 0.851 -> 0.810 ms.
+int widen_for_large_tiles(int wpo, const PnpArgs &a, int flags, int in_dtype) {
+    if ((flags & MR_WAVES_MASK) || wpo != 4 || in_dtype == MR_F64 || a.P < 64 * 8 * 2) return wpo;
+    PnpArgs t = a;
+    t.elem_size = (in_dtype == MR_F16) ? 2 : 4;                 // the launcher sets it later, from the template type
+    return (lds_bytes(t, 4) * 3 > (size_t)160 * 1024) ? 8 : wpo;
+}
+
 // 6-DoF refinement (second launch of pnp_uncert(..., use_6dof=True)): see pnp6_kernel.inc
 template <typename T>
 int launch_pnp6(Pnp6Args &a, hipStream_t st) {
@@ -578,7 +588,7 @@ int mr_pnp_uncert_batched(
     if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
-    const int wpo = pick_wpo(B, P, flags);
+    const int wpo = widen_for_large_tiles(pick_wpo(B, P, flags), a, flags, in_dtype);
     hipStream_t st = (hipStream_t)stream;
     switch (in_dtype) {
         case MR_F32: return launch_wpo<float>(a, wpo, st);
@@ -734,7 +744,7 @@ int mr_pnp_from_head_batched(
     if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
-    return launch_wpo<float>(a, pick_wpo(B, P, flags), (hipStream_t)stream);
+    return launch_wpo<float>(a, widen_for_large_tiles(pick_wpo(B, P, flags), a, flags, MR_F32), (hipStream_t)stream);
 }
 
 int mr_roi_align_avg(const float *input, const float *rois, int K, int C, int H, int W, int out_h, int out_w,
