@@ -339,3 +339,21 @@ def test_fused_head_to_pose_on_70000_objects(dev):
         tiles = big[k].view(rep, nd, *big[k].shape[1:])
         assert torch.equal(tiles[0], small[k]), k
         assert bool((tiles == tiles[:1]).all()), k
+
+
+@pytest.mark.gpu
+def test_fused_path_on_56x56_tiles(dev):
+    """The config-5 RoI resolution through the pose head: 100 KB tiles, for which the library picks 8 waves per object
+    (at most two workgroups fit a CU) — one launch equals decode + PnP launch bit for bit."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
+    b = syn.make_batch(B=64, hw=56, seed=5)
+    all_pred, dim = syn.encode_head_outputs(b, seed=5)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    head = UncertPropPnPOptimizer().to(dev)
+    args = (head, t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), (syn.IMG_H, syn.IMG_W, 3))
+    with torch.no_grad():
+        r1, r2 = pose_from_head(*args), pose_from_head(*args, fused=False)
+    torch.cuda.synchronize()
+    assert int(r1['ret_val'].sum()) >= 60
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'inlier_mask', 'dimensions_pred'):
+        assert torch.equal(r1[k], r2[k]), k
