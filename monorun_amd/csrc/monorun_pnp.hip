@@ -22,6 +22,10 @@ constexpr int kMaxDevices = 64;     // per-device library state (LDS opt-in, hos
 #ifndef MR_MIN_WAVES
 #define MR_MIN_WAVES 3              // waves per SIMD the register allocator must allow: fp64 storage (<= 168 VGPRs)
 #endif
+#ifndef MR_RELAXED_WPO
+#define MR_RELAXED_WPO 2            // instantiations with at most this many waves per object are compiled for 3 waves per SIMD (168 VGPRs):
+                                    // they serve large batches, where LDS allows 5 workgroups = 10 waves per CU anyway; 8192-object launch 297 -> 289 us
+#endif
 #ifndef MR_MIN_WAVES_F32
 #define MR_MIN_WAVES_F32 4          // fp32 and 16-bit storage (the pipeline's cases): <= 128 VGPRs, so that the 1024 four-wave blocks of a
 #endif                              // config-2 launch are all resident (measured: 76 us vs 83 us when the allocator lands on 139 VGPRs)
