@@ -58,6 +58,9 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary figures (multi-stream, 8192-object launch, per-image latency)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='target CPU-baseline sample time (all legs together)')
     ap.add_argument('--waves', type=int, default=0, help='wavefronts per object (0 = library heuristic)')
+    ap.add_argument('--in-flight', type=int, default=int(os.environ.get('MR_BENCH_IN_FLIGHT', '4')),
+                    help='launches in flight: the steps are issued round-robin on this many HIP streams through monorun_amd.PnPPipeline '
+                         '(1 = one stream, every launch waits for the previous one; reported as single_stream either way)')
     ap.add_argument('--workload', choices=['config2', 'stress'], default='config2',
                     help="config2 (default, the metric's configuration) or stress = BASELINE config 5's per-GPU shard: 8192 objects x "
                          '56x56 correspondences, fp16 storage (a parity-test shape; an extra line, never the judged one)')
@@ -160,7 +163,7 @@ def run(args):
     import torch
     import torch.distributed as dist
     from monorun_amd import synthetic as syn
-    from monorun_amd import PnPLaunch
+    from monorun_amd import PnPLaunch, PnPPipeline
     from monorun_amd.parallel import PackedResults, ROW_BYTES
 
     stress = args.workload == 'stress'
@@ -170,6 +173,7 @@ def run(args):
         BYTES_PER_SOLVE = P * 7 * 2 + 36 + 16 + 4 + 16 + 64 + 4 + 1 + P
         args.no_cpu_baseline = args.no_secondary = True
         args.batches = 1                         # one 8192-object fp16 batch is 360 MB: already larger than the Infinity Cache
+        args.in_flight = 1                       # an 8192-object launch fills the chip by itself
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -236,101 +240,194 @@ def run(args):
         except Exception as e:                                   # noqa: BLE001 — any setup problem: use the c10d path
             print(f'[bench] direct RCCL path unavailable ({e}); using torch.distributed', file=sys.stderr)
             rccl = None
-    # Result buffers: a ring of RING groups of G slots.  One step fills one slot (the kernel writes straight into it); a group —
-    # G consecutive steps' results, one contiguous buffer — is exchanged with ONE all-gather ("fewer, larger collectives": the
-    # message is latency-bound either way, 88 KiB per step and rank), on the side stream, while the following steps compute.
-    # Why groups: every command on the side queue and every cross-stream dependency costs the COMPUTE stream ~5 us on this stack
-    # (tools/rccl_step_cost.py: record 3.5, side-stream collective 5, wait or query on its event 5), so they are paid once per G
-    # steps.  Why a ring: the collective couples the ranks and a launch lasts as long as its slowest object (56 - 98 us between
-    # batches); a rank may run RING - 1 groups ahead of the slowest one instead of stalling on every step's slowest launch.
-    RING = max(2, int(os.environ.get('MR_BENCH_RING', '4'))) if use_dist else 1
-    G = max(1, int(os.environ.get('MR_BENCH_GATHER_EVERY', '8'))) if rccl is not None else 1
-    S = RING * G
+    # Launches in flight.  One launch of 1024 objects lasts as long as its slowest object, and launches on one stream serialise;
+    # the product's PnPPipeline issues the steps round-robin on L streams so that the next batches fill the SIMDs a launch's tail
+    # leaves idle.  Every step is still ONE full config-2 launch over its own batch into its own result buffers.
+    pipes = {}
+
+    def pipe_of(depth):
+        if depth not in pipes:      # the streams are picked by measurement: mutually overlapping, and not on the exchange's queue
+            pipes[depth] = PnPPipeline(dev, depth=depth, avoid=[rccl.stream] if rccl is not None else ())
+        return pipes[depth]
+    L_ASKED = max(1, args.in_flight)
+    L = pipe_of(L_ASKED).depth                         # launches really in flight (streams found to run side by side)
+    # Result buffers: S slots (packed 88 B/object rows + inlier masks), slot s pinned to pipeline stream s % L.  With N > 1 every
+    # step's packed rows are exchanged by ONE all-gather (north_star: "RCCL all-gather of poses"; G = 1 by default) on the side
+    # stream, behind that step's completion event, while the following steps compute.  MR_BENCH_GATHER_EVERY=G groups G
+    # consecutive steps (one contiguous G x 88 KiB buffer) into one collective: measured as secondary_throughput.grouped_collective.
+    G_SEC = 8
+    RING = max(2, int(os.environ.get('MR_BENCH_RING', '4')))
+    S = RING * G_SEC                                   # 32 slots: multiple of every L <= 8 and of G_SEC
+    while S % L:
+        S += G_SEC
     row = B_PER_GPU * ROW_BYTES
-    gbuf = [torch.zeros(G * row, dtype=torch.uint8, device=dev) for _ in range(RING)]
-    packs = [PackedResults(B_PER_GPU, dev, buf=gbuf[sl // G][(sl % G) * row:(sl % G + 1) * row]) for sl in range(S)]
+    gbuf = [torch.zeros(G_SEC * row, dtype=torch.uint8, device=dev) for _ in range(S // G_SEC)]
+    packs = [PackedResults(B_PER_GPU, dev, buf=gbuf[sl // G_SEC][(sl % G_SEC) * row:(sl % G_SEC + 1) * row]) for sl in range(S)]
     masks = [torch.empty(B_PER_GPU, P, device=dev, dtype=torch.uint8) for _ in range(S)]
 
-    def mk(bi, k, **kw):
+    # waves per object: --waves, else the pipeline's rule (the library's own rule applied to the objects of all launches in flight)
+    fl_main = (args.waves << 8) if args.waves else pipe_of(L_ASKED).flags_for(B_PER_GPU, P)
+    fl_one = (args.waves << 8)                              # one launch at a time: the library's heuristic
+
+    def mk(bi, k, flags=None, **kw):
         x2d, istd, x3d, K, ur, vr, thr = dev_batches[bi]
         return PnPLaunch(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr, inlier_opt_only=True,
-                         flags=(args.waves << 8), out=packs[k] if k is not None else None, mask=masks[k] if k is not None else None, **kw)
+                         flags=fl_main if flags is None else flags, out=packs[k] if k is not None else None, mask=masks[k] if k is not None else None, **kw)
     launches = [[mk(bi, k) for k in range(S)] for bi in range(NB)]
-    gathered = [torch.empty(world * b.numel(), dtype=torch.uint8, device=dev) for b in gbuf] if use_dist else None
-    comm = None
+    launches_one = launches if fl_one == fl_main else [[mk(bi, k, flags=fl_one) for k in range(S)] for bi in range(NB)]
+    gathered_step = [torch.empty(world * row, dtype=torch.uint8, device=dev) for _ in range(S)] if use_dist else None
+    gathered_grp = [torch.empty(world * b.numel(), dtype=torch.uint8, device=dev) for b in gbuf] if use_dist else None
     if use_dist and oversub:
-        comm = {'backend': 'gloo (host-staged; MR_BENCH_OVERSUBSCRIBE test mode: several ranks share one GPU, which RCCL refuses)',
-                'nranks': dist.get_world_size(), 'bytes_per_rank': row}
         host_send = torch.empty(row, dtype=torch.uint8).pin_memory()
         host_recv = torch.empty(world * row, dtype=torch.uint8).pin_memory()
-    elif use_dist:
-        comm = {'backend': 'rccl (private communicator, ncclAllGather on a side stream, overlapped with the following steps)' if rccl is not None
-                else 'rccl via torch.distributed (nccl backend) all_gather_into_tensor',
-                'nranks': rccl.nranks() if rccl is not None else dist.get_world_size(),
-                'bytes_per_rank': G * row, 'steps_per_collective': G, 'result_ring_groups': RING}
-    done = [None] * RING
-    counter = [0]
+    class Loop:
+        """K steps of the hot path: launch (+ exchange).  depth = launches in flight, G = steps per collective."""
 
-    def step():
-        i = counter[0]
-        counter[0] += 1
-        bi = (i + rot0) % NB
-        if not use_dist:
-            launches[bi][0].run()
-            return
-        sl = i % S
-        g, j = sl // G, sl % G
-        if oversub:
-            launches[bi][sl].run()
-            host_send.copy_(packs[sl].buf, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            dist.all_gather_into_tensor(host_recv, host_send)
-            gathered[g].copy_(host_recv, non_blocking=True)
-            return
-        if rccl is None:
-            launches[bi][sl].run()
-            dist.all_gather_into_tensor(gathered[g], gbuf[g])
-            return
-        if j == 0 and done[g] is not None:
-            # group g is about to be rewritten: its previous exchange (RING groups ago) must have finished; normally it has, long ago
-            if not done[g].query():
-                torch.cuda.current_stream().wait_event(done[g])
-            done[g] = None
-        launches[bi][sl].run()
-        if j == G - 1:
-            done[g] = rccl.gather(gbuf[g], gathered[g])
+        def __init__(self, depth, G):
+            self.depth, self.G = depth, (G if rccl is not None else 1)
+            self.pipe = pipe_of(L_ASKED if depth == L else depth)
+            self.launches = launches if depth == L else launches_one
+            self.done = [None] * S          # completion event of the collective that last READ slot s (or its group)
+            self.evs = [None] * S           # completion event of the launch that last WROTE slot s
+            self.i = 0
 
-    def fence():
-        if use_dist:
-            if rccl is not None and counter[0] % G != 0:           # a group that is only partly filled: exchange it as it is
-                g = ((counter[0] - 1) % S) // G
-                done[g] = rccl.gather(gbuf[g], gathered[g])
-            for k in range(RING):
-                if done[k] is not None:
-                    torch.cuda.current_stream().wait_event(done[k])
-                    done[k] = None
+        def step(self):
+            i = self.i
+            self.i += 1
+            bi = (i + rot0) % NB
+            sl = i % S
+            if not use_dist:
+                self.evs[sl] = self.pipe.submit(self.launches[bi][sl], slot=sl)
+                return
+            k = sl % self.depth
+            if oversub:
+                self.pipe.submit(self.launches[bi][sl], slot=sl).synchronize()
+                host_send.copy_(packs[sl].buf)
+                dist.all_gather_into_tensor(host_recv, host_send)
+                gathered_step[sl].copy_(host_recv, non_blocking=True)
+                return
+            if rccl is None:
+                ev = self.pipe.submit(self.launches[bi][sl], slot=sl)
+                torch.cuda.current_stream().wait_event(ev)
+                dist.all_gather_into_tensor(gathered_step[sl], packs[sl].buf)
+                return
+            G = self.G
+            g0 = sl - sl % G                                        # first slot of this step's group
+            d = self.done[g0]
+            if d is not None and sl == g0:
+                # the group is about to be rewritten: its previous exchange (S steps ago) must have finished; normally it has, long ago
+                if not d.query():
+                    for kk in range(min(self.depth, G)):
+                        self.pipe.streams[(sl + kk) % self.depth].wait_event(d)
+                self.done[g0] = None
+            self.evs[sl] = self.pipe.submit(self.launches[bi][sl], slot=sl)
+            if sl % G == G - 1:
+                self.exchange(g0, sl)
+
+        def exchange(self, g0, last):
+            G = self.G
+            if G == 1:
+                self.done[g0] = rccl.gather(packs[last].buf, gathered_step[last], after=self.evs[last])
+                return
+            # the group's steps ran on min(depth, G) different streams: the collective waits for the last launch of each
+            for sl in range(max(g0, last - self.depth + 1), last):
+                rccl.stream.wait_event(self.evs[sl])
+            gi = g0 // G_SEC
+            nb = (last - g0 + 1) * row                               # a partly filled group at the fence: what there is
+            send = gbuf[gi] if nb == gbuf[gi].numel() else gbuf[gi][:nb]
+            recv = gathered_grp[gi] if nb == gbuf[gi].numel() else gathered_grp[gi][:world * nb]
+            self.done[g0] = rccl.gather(send, recv, after=self.evs[last])
+
+        def fence(self):
+            if use_dist and rccl is not None and self.G > 1 and self.i % self.G != 0:
+                last = (self.i - 1) % S
+                self.exchange(last - last % self.G, last)
+            self.pipe.drain()
+            if use_dist:
+                if rccl is not None:
+                    rccl.stream.synchronize()
+                torch.cuda.synchronize()
+                dist.barrier()
             torch.cuda.synchronize()
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if oversub else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def timed(self, steps, warmup):
+            for _ in range(warmup):
+                self.step()
+            self.fence()
+            self.i = 0                                               # the timed window starts at rotation offset 0 (+ the rank's offset)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            t_issue = time.perf_counter() - t0
+            self.fence()
+            el = time.perf_counter() - t0
+            if os.environ.get('MR_BENCH_DEBUG'):
+                print(f'[bench] depth {self.depth} G {self.G}: {steps} steps issued in {t_issue * 1e6:.0f} us ({t_issue / steps * 1e6:.1f} us/step), complete after {el * 1e6:.0f} us', file=sys.stderr)
+            if use_dist:
+                t = torch.tensor([el], dtype=torch.float64, device='cpu' if oversub else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el
+
+    G_MAIN = max(1, int(os.environ.get('MR_BENCH_GATHER_EVERY', '1')))
+    if G_MAIN not in (1, G_SEC):
+        G_MAIN = 1
+    main_loop = Loop(L, G_MAIN)
+    elapsed = main_loop.timed(args.steps, args.warmup)
     gather_ok = None
     if use_dist:                                 # the gathered buffer holds every rank's rows (rank-major): check this rank's slice
         torch.cuda.synchronize()
-        g = ((counter[0] - 1) % S) // G
-        n = gbuf[g].numel()
-        gather_ok = bool(torch.equal(gathered[g][rank * n:(rank + 1) * n], gbuf[g]))
+        sl = (main_loop.i - 1) % S
+        if main_loop.G == 1:
+            gather_ok = bool(torch.equal(gathered_step[sl][rank * row:(rank + 1) * row], packs[sl].buf))
+        else:
+            gi = sl // G_SEC
+            nb = (sl % G_SEC + 1) * row
+            gather_ok = bool(torch.equal(gathered_grp[gi][rank * nb:(rank + 1) * nb], gbuf[gi][:nb]))
+    # every slot written inside the timed window holds exactly what an isolated launch of the same batch produces
+    outputs_ok = True
+    for i in range(max(0, main_loop.i - S), main_loop.i):
+        bi, sl = (i + rot0) % NB, i % S
+        ref = PnPLaunch(*dev_batches[bi][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[bi][6], inlier_opt_only=True, flags=fl_main)
+        ref.run()
+        torch.cuda.synchronize()
+        outputs_ok = outputs_ok and bool(torch.equal(ref.pose, packs[sl].pose) and torch.equal(ref.cov, packs[sl].cov) and
+                                         torch.equal(ref.valid, packs[sl].valid) and torch.equal(ref.mask, masks[sl]))
+    assert outputs_ok, 'a pipelined launch produced results that differ from an isolated launch of the same batch'
+    # the same loop over a whole number of rotations (the driver's --steps need not be a multiple of --batches, and the batches
+    # take 56 - 98 us each), and on ONE stream (every launch waits for the previous one: what rounds 1 and 2 reported as `value`)
+    variants = {}
+    full = ((args.steps + NB - 1) // NB) * NB
+    variants['rotation_normalised'] = {'steps': full, 'elapsed': Loop(L, G_MAIN).timed(full, min(args.warmup, NB))}
+    if L != 1:
+        variants['single_stream'] = {'steps': full, 'elapsed': Loop(1, G_MAIN).timed(full, min(args.warmup, NB))}
+    if use_dist and rccl is not None:
+        variants['grouped_collective'] = {'steps': full, 'elapsed': Loop(L, G_SEC if G_MAIN == 1 else 1).timed(full, min(args.warmup, NB)),
+                                          'steps_per_collective': G_SEC if G_MAIN == 1 else 1}
+    comm = None
+    if use_dist and oversub:
+        comm = {'backend': 'gloo (host-staged; MR_BENCH_OVERSUBSCRIBE test mode: several ranks share one GPU, which RCCL refuses)',
+                'nranks': dist.get_world_size(), 'bytes_per_rank': row, 'steps_per_collective': 1}
+    elif use_dist:
+        comm = {'backend': 'rccl (private communicator, ncclAllGather on a side stream behind the step\'s completion event, overlapped with the following steps)' if rccl is not None
+                else 'rccl via torch.distributed (nccl backend) all_gather_into_tensor',
+                'nranks': rccl.nranks() if rccl is not None else dist.get_world_size(),
+                'bytes_per_rank': main_loop.G * row, 'steps_per_collective': main_loop.G, 'result_slots': S}
+        if rccl is not None:
+            # duration of the collective itself: timing events on the side stream around isolated all-gathers of one step's rows
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(20)]
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(20)]
+            torch.cuda.synchronize(); dist.barrier()
+            for k in range(20):
+                e0[k].record(rccl.stream)
+                rccl.lib.ncclAllGather(packs[0].buf.data_ptr(), gathered_step[0].data_ptr(), row, rccl.NCCL_UINT8, rccl.comm, rccl.stream.cuda_stream)
+                e1[k].record(rccl.stream)
+            rccl.stream.synchronize()
+            us = float(np.median([a.elapsed_time(b) for a, b in zip(e0[5:], e1[5:])])) * 1e3
+            comm['us_per_collective'] = us
+            comm['algbw_GBps'] = world * row / (us * 1e-6) / 1e9
+            comm['algbw_definition'] = 'bytes every rank ends up with (nranks x bytes_per_rank at 1 step per collective) / median duration of an isolated collective'
+    main_loop = None
 
     # dominant-kernel duration: HIP events around each launch on the launch stream (torch's current stream), rotating batches
     n_ev = min(max(args.steps, NB), 240)
@@ -338,7 +435,7 @@ def run(args):
     torch.cuda.synchronize()
     for i, (e0, e1) in enumerate(evs):
         e0.record()
-        launches[i % NB][0].run()
+        launches_one[i % NB][0].run()
         e1.record()
     torch.cuda.synchronize()
     k_ms = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
@@ -407,7 +504,11 @@ def run(args):
                                          'resident, more than the 256 MiB Infinity Cache' + (f'; every rank holds the same {NB} batches and starts '
                                          f'the rotation at offset rank*{NB}//{world} (distinct batches across ranks at every step, equal work per rotation)' if world > 1 else ''),
                        'stages': 'istd mask + K0 consensus initialiser (32 hyp.) + LM (Ceres-1.14 semantics, fp64) + covariance',
-                       'parallelism': f'objects sharded x{world}' + (', 1 all-gather of 88 B/object per step' if world > 1 else '')},
+                       'launches_in_flight': L, 'launches_in_flight_asked': L_ASKED, 'stream_overlap_test': pipe_of(L_ASKED).overlap_test, 'waves_per_object': {'in_flight': (fl_main >> 8) & 15 or 'library heuristic (4)', 'isolated_launch': (fl_one >> 8) & 15 or 'library heuristic (4)'},
+                       'issue': (f'steps issued round-robin on {L} HIP streams by monorun_amd.PnPPipeline (one completion event per result buffer); '
+                                 'every step is one full 1024-object launch into its own buffers, all outputs complete inside the timed window '
+                                 'and verified bit-identical to isolated launches after it') if L > 1 else 'one stream: every launch waits for the previous one',
+                       'parallelism': f'objects sharded x{world}' + (f', 1 all-gather of 88 B/object x {comm["steps_per_collective"]} step(s) per collective' if (world > 1 and comm) else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
                          'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)),
@@ -424,8 +525,26 @@ def run(args):
                          'note': 'formally HBM-bound (read-once streaming); in practice VALU/latency-bound: the tile is LDS-resident '
                                  'across all LM iterations (DESIGN.md)'},
             'valid_fraction': valid_frac,
+            'outputs_verified': outputs_ok,
             'secondary_throughput': extra,
         }
+        def per_s(v):
+            return {'value': B_PER_GPU * world * v['steps'] / v['elapsed'], 'unit': 'solves/s', 'ms_per_step': v['elapsed'] / v['steps'] * 1e3, 'steps': v['steps']}
+        rn = per_s(variants['rotation_normalised'])
+        line['value_rotation_normalised'] = rn['value']
+        line['rotation_normalised'] = dict(rn, what=f'the same loop timed over {rn["steps"]} steps = a whole number of rotations over the {NB} batches '
+                                                    '(--steps need not be a multiple of --batches, and the batches take different times)')
+        if 'single_stream' in variants:
+            line['single_stream'] = dict(per_s(variants['single_stream']), what='the same steps on ONE stream (launches_in_flight = 1): every launch '
+                                         'waits for the previous one and so pays its slowest object; what rounds 1-2 reported as `value`')
+        if 'grouped_collective' in variants:
+            extra['grouped_collective'] = dict(per_s(variants['grouped_collective']), steps_per_collective=variants['grouped_collective']['steps_per_collective'],
+                                               what='the same loop with the other exchange granularity (one all-gather per this many steps)')
+        line['roofline']['in_flight'] = {
+            'launches_in_flight': L, 'achieved': line['value'] / world * BYTES_PER_SOLVE / 1e9, 'unit': 'GB/s',
+            'frac': line['value'] / world * BYTES_PER_SOLVE / 1e9 / HBM_PEAK_GBS,
+            'note': 'chip-level rate of the timed region: algorithmic bytes of ALL launches / wall time (launches overlap, so this is not a '
+                    'per-launch duration); `achieved` / `frac` above are per launch, from HIP events around isolated launches on one stream'}
         if comm is not None:
             comm['gathered_rows_verified'] = gather_ok
             line['comm'] = comm
@@ -523,12 +642,88 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
             'what': 'host wall per call incl. output allocation and argument marshalling, 1024 objects, after the 4-DoF solve of batch 0'}
     except Exception as e:                                          # noqa: BLE001 — secondary figure
         extra['second_launches'] = {'error': repr(e)}
+    # (f) the NOC path at B = 1024: raw head output -> pose, fused (one launch) and as two launches (K2 decode, then the PnP kernel)
+    try:
+        extra['head_to_pose_1024'] = head_to_pose(torch, syn, PnPLaunch, dev)
+    except Exception as e:                                          # noqa: BLE001 — secondary figure
+        extra['head_to_pose_1024'] = {'error': repr(e)}
     # (d) the deployment regime (monorun_roi_head.py:452: one image per forward, <= 100 proposals): per-call latency
     try:
         extra['per_image_B100'] = per_image_latency(torch, syn, dev, batch0, args)
     except Exception as e:                                          # noqa: BLE001 — secondary figure: report, do not fail the line
         extra['per_image_B100'] = {'error': repr(e)}
     return extra
+
+
+def graph_us_per_launch(torch, fns, reps=20):
+    """Average GPU time of one launch of `fns` (a list of enqueue-only callables) when they run back to back: the sequence is
+    captured into ONE HIP graph and replayed `reps` times between two events — no host launch latency between the kernels, the
+    ~1.5 us kernel boundary included."""
+    for f in fns:
+        f()                                                          # warm-up outside the capture (LDS opt-in, lazy module load)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for f in fns:
+            f()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * len(fns))
+
+
+def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=3):
+    """B = 1024 objects from the RAW NOC-head output (1024 x 30 x 28 x 28 fp32 = 96 MB per batch, 3 distinct resident batches =
+    289 MB > the Infinity Cache) to poses: K2 alone (`noc_decode_kernel`, the one HBM-bound kernel of the path), K2 + PnP as two
+    launches, and the fused one-launch kernel; each with its algorithmic bytes against the 8 TB/s HBM roofline."""
+    from monorun_amd.pose_head import NocDecodeLaunch, PoseFromHeadLaunch, UncertPropPnPOptimizer, _planar_view, _clip_ranges
+    head = UncertPropPnPOptimizer().to(dev)
+    k2s, fus, pnps = [], [], []
+    for i in range(n_batches):
+        b = syn.make_batch(B=B_PER_GPU, hw=HW, seed=SEED + 7919 * i)
+        all_pred, dim = syn.encode_head_outputs(b, seed=SEED + i)
+        rng = np.random.default_rng(SEED + i)
+        dim_var = torch.from_numpy((0.01 * rng.random((B_PER_GPU, 3)) + 1e-4).astype(np.float32)).to(dev)      # MC-dropout variance of the dims (test time)
+        ap, lab, dm, rois = (torch.from_numpy(all_pred).to(dev), torch.from_numpy(b['labels']).to(dev), torch.from_numpy(dim).to(dev),
+                             torch.from_numpy(b['rois']).to(dev))
+        K = torch.from_numpy(b['K']).to(dev)
+        k2 = NocDecodeLaunch(ap, lab, False, dm, dim_var, rois)
+        ur, vr = _clip_ranges((syn.IMG_H, syn.IMG_W), head.allowed_border, dev)
+        d = k2.out
+        pn = PnPLaunch(_planar_view(d['coords_2d']), _planar_view(d['coords_2d_istd']), _planar_view(d['coords_3d']), K, ur, vr, z_min=0.5,
+                       epnp_istd_thres=0.6, epnp_ransac_thres=d['ransac_thr'], inlier_opt_only=True)
+        fu = PoseFromHeadLaunch(head, ap, lab, False, dm, dim_var, rois, K, (syn.IMG_H, syn.IMG_W))
+        k2s.append(k2); pnps.append(pn); fus.append(fu)
+    px = B_PER_GPU * P
+    bytes_k2 = px * (5 * 4 + 7 * 4) + B_PER_GPU * (20 + 24 + 8 + 12 + 12 + 4)
+    bytes_fused = B_PER_GPU * (P * 5 * 4 + 20 + 24 + 8 + 16 + 64 + 4 + 1 + P + 64 + 12 + 12)
+    t_k2 = graph_us_per_launch(torch, [k.run for k in k2s] * 4)
+    t_two = graph_us_per_launch(torch, [f for k, q in zip(k2s, pnps) for f in (k.run, q.run)] * 2) * 2       # per (K2, PnP) pair
+    t_fu = graph_us_per_launch(torch, [f.run for f in fus] * 2)
+    # the two paths run the same device functions in the same order: identical results
+    k2s[0].run(); pnps[0].run(); fus[0].run()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(pnps[0].pose, fus[0].out['pose']) and torch.equal(pnps[0].mask, fus[0].out['inlier_mask_u8']))
+
+    def roof(nbytes, us):
+        ach = nbytes / (us * 1e-6) / 1e9
+        return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': nbytes}
+    return {
+        'k2_noc_decode': {'us_per_launch': t_k2, 'value': B_PER_GPU / (t_k2 * 1e-6), 'unit': 'objects/s', 'roofline': roof(bytes_k2, t_k2),
+                          'bytes_model': '48 B per RoI pixel (5 selected head channels read, 7 decoded channels written, fp32) + per-object vectors'},
+        'two_launch': {'us_per_pair': t_two, 'value': B_PER_GPU / (t_two * 1e-6), 'unit': 'solves/s',
+                       'roofline': roof(bytes_k2 + BYTES_PER_SOLVE * B_PER_GPU, t_two)},
+        'fused': {'us_per_launch': t_fu, 'value': B_PER_GPU / (t_fu * 1e-6), 'unit': 'solves/s', 'roofline': roof(bytes_fused, t_fu),
+                  'bytes_model': '20 B per RoI pixel read (the decoded maps never exist in HBM) + per-object inputs + pose / cov / calibrated cov / mask written'},
+        'fused_equals_two_launch': same,
+        'how': f'{n_batches} distinct resident head outputs ({n_batches * B_PER_GPU * 30 * P * 4 / 2**20:.0f} MiB), launches captured into one HIP graph and replayed '
+               '(no host latency between kernels); one stream, so the PnP launches pay their slowest object',
+    }
 
 
 def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):

@@ -60,6 +60,8 @@ extern "C" {
 #define MR_COV_NONE           0x8     /* do not compute the pose covariance (cov left untouched) */
 #define MR_COV_CERES          0x10    /* covariance with the solver's (Ceres/autodiff) Jacobian instead of the
                                          torch Jacobian of jacobian.py (what `pnp_uncert`'s result_cov is) */
+#define MR_ANY_ORDER          0x20    /* the launch may start before earlier work on the same stream has finished (hipExtAnyOrderLaunch:
+                                         no barrier bit on the dispatch); the caller orders consumers with events.  Experimental */
 #define MR_WAVES_SHIFT        8       /* bits 8..11: wavefronts cooperating on one object (0 = auto, 1,2,4,8) */
 #define MR_WAVES_MASK         (0xF << MR_WAVES_SHIFT)
 #define MR_LM_MAXIT_SHIFT      16      /* bits 16..21: Ceres' max_num_iterations for the LM (0 = the default, 50; 1..63) */
@@ -77,6 +79,8 @@ int mr_pnp_version(void);
 const char *mr_pnp_error_string(int code);
 int mr_pnp_last_hip_error(void);
 int mr_pnp_device_count(void);
+/* one wavefront busy for `microseconds` on `stream` (stream-overlap self-test of the Python pipeline; asynchronous) */
+int mr_spin(int microseconds, void *stream);
 
 /*
  * Batched uncertainty-aware PnP: for each of B objects with P correspondences

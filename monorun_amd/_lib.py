@@ -17,7 +17,7 @@ SO = os.environ.get('MR_PNP_SO') or os.path.join(_HERE, 'libmonorun_pnp.so')    
 
 MR_F32, MR_F16, MR_F64, MR_BF16 = 0, 1, 2, 3
 MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
-MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES = 0x4, 0x8, 0x10
+MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES, MR_ANY_ORDER = 0x4, 0x8, 0x10, 0x20
 MR_WAVES_SHIFT = 8
 MR_LM_MAXIT_SHIFT = 16
 
@@ -64,6 +64,8 @@ def load():
     lib.mr_pnp_error_string.argtypes = [i32]
     lib.mr_pnp_last_hip_error.restype = i32
     lib.mr_pnp_device_count.restype = i32
+    lib.mr_spin.restype = i32
+    lib.mr_spin.argtypes = [i32, vp]
     lib.mr_pnp_uncert_batched.restype = i32
     lib.mr_pnp_uncert_batched.argtypes = [
         vp, i64p, vp, i64p, vp, i64p, i32,          # x2d, istd, x3d (+strides), in_dtype
@@ -119,6 +121,6 @@ def check(code):
                            f'(code {code}, hip error {lib.mr_pnp_last_hip_error()})')
 
 
-EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
+EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_spin', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
                     'mr_pnp_uncert_batched', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
                     'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

@@ -2,6 +2,7 @@
 // The C ABI is declared in include/monorun_pnp.h; the fused per-object kernel lives in pnp_kernel.inc.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string.h>
 #include <atomic>
@@ -188,6 +189,7 @@ __device__ __forceinline__ void decode_object(const DecodeArgs &a, int b, Decode
     o.ch_noc = f * 5 * Cn + 3 * c; o.ch_ls = f * 5 * Cn + 3 * Cn + 2 * c;
 }
 
+// (the scalar form, textually what the fused PnP kernel has been tuned around: its code must not move — tools/isa_diff.sh)
 __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeObj &o, int p, float (&c2d)[2], float (&istd)[2], float (&c3d)[3]) {
 #pragma clang fp contract(off)
     const int hw = a.h * a.w;
@@ -204,6 +206,36 @@ __device__ __forceinline__ void decode_pixel(const DecodeArgs &a, const DecodeOb
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float ls = pred_at(a, o.base + (long long)(o.ch_ls + k) * hw + p);
+        float lspx;
+        if (a.has_var) lspx = 0.5f * mr_logf((v2[k] * a.k_epi + mr_expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
+        else lspx = ls + 0.0f;                                    // log(sd / sd)
+        istd[k] = mr_expf(-lspx) / a.std_scale;
+    }
+    if (a.map2d) {      // roi_align(coord_2d, rois, (h, w), 1.0, 0, 'avg', True)   (monorun_roi_head.py:521-523)
+        c2d[0] = roi_align_avg_bin(a.map2d, a.map_h, a.map_w, o.x1, o.y1, o.x2, o.y2, py, px, a.h, a.w, 0, 1);
+        c2d[1] = roi_align_avg_bin(a.map2d + (long long)a.map_h * a.map_w, a.map_h, a.map_w, o.x1, o.y1, o.x2, o.y2, py, px, a.h, a.w, 0, 1);
+    } else {            // interior analytic form: the bin centre of an identity coordinate map
+        c2d[0] = (o.x1 - 0.5f) + ((float)px + 0.5f) * o.su;
+        c2d[1] = (o.y1 - 0.5f) + ((float)py + 0.5f) * o.sv;
+    }
+}
+
+// the same arithmetic from five head-channel VALUES (the vector kernel loads them four pixels at a time); analytic grid only
+__device__ __forceinline__ void decode_pixel_vals(const DecodeArgs &a, const DecodeObj &o, int p, const float (&nocv)[3], const float (&lsv)[2],
+                                                  float (&c2d)[2], float (&istd)[2], float (&c3d)[3]) {
+#pragma clang fp contract(off)
+    const int py = p / a.w, px = p - py * a.w;
+    float xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float part = nocv[k] * o.ns[k] + o.nm[k];
+        c3d[k] = part * o.dm[k];
+        xv[k] = o.dv[k] * (part * part);
+    }
+    const float v2[2] = { 0.5f * (xv[0] + xv[2]), xv[1] };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float ls = lsv[k];
         float lspx;
         if (a.has_var) lspx = 0.5f * mr_logf((v2[k] * a.k_epi + mr_expf(2.0f * ls) * a.k_sd2) / a.sd_sq);
         else lspx = ls + 0.0f;                                    // log(sd / sd)
@@ -240,6 +272,68 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
     for (int k = 0; k < 3; ++k) a.c3d[((long long)b * 3 + k) * hw + p] = c3d[k];
 #pragma unroll
     for (int k = 0; k < 2; ++k) { a.istd[((long long)b * 2 + k) * hw + p] = istd[k]; a.c2d[((long long)b * 2 + k) * hw + p] = c2d[k]; }
+}
+
+// K2, vector form: one thread per FOUR consecutive RoI pixels of one object — five 16-byte loads of the selected head channels,
+// seven 16-byte stores of the decoded channels (the scalar kernel above moves 4 bytes per lane and instruction and leaves the last
+// of an object's ceil(784/256) = 4 blocks 94 % idle: 15.1 us per 1024 x 28x28 batch = 32 % of the HBM roofline).  One workgroup per
+// object (grid = B).  Same per-pixel arithmetic, hence bit-identical outputs.  Requires fp32 head output,
+// h*w % 4 == 0, no coord_2d map (the launcher falls back to the scalar kernel otherwise).
+template <int THREADS, int TRIPS>
+__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj) {
+    // one workgroup per object: the object index is wave-uniform, so its parameters (label, flip, dims, RoI, coder constants — two
+    // dependent rounds of loads) are fetched through the scalar cache once per wave instead of once per lane.  A thread takes up
+    // to TRIPS pixel quads (q = t, t + THREADS, ...): all their loads are issued before the first quad is decoded, so the
+    // arithmetic of one quad (the specified exp / log sequences and IEEE divisions: ~300 instructions per pixel) overlaps the
+    // loads of the next and the stores of the previous one.
+    const int b = blockIdx.x;
+    const int hw = a.h * a.w;
+    DecodeObj o;
+    decode_object(a, b, o);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (a.dims) a.dims[b * 3 + k] = o.dm[k];
+            if (a.dims_var && a.has_var) a.dims_var[b * 3 + k] = o.dv[k];
+        }
+        if (a.thr) a.thr[b] = o.thr;
+    }
+    const float *ap = (const float *)a.all_pred;
+    for (int q0 = threadIdx.x; q0 < quads_per_obj; q0 += THREADS * TRIPS) {
+        float4 in[TRIPS][5];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int q = q0 + t * THREADS;
+            if (q < quads_per_obj) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) in[t][k] = *(const float4 *)(ap + o.base + (long long)(o.ch_noc + k) * hw + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) in[t][3 + k] = *(const float4 *)(ap + o.base + (long long)(o.ch_ls + k) * hw + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int q = q0 + t * THREADS;
+            if (q >= quads_per_obj) break;
+            const int p0 = 4 * q;
+            float out[7][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float noc[3] = { ((const float *)&in[t][0])[j], ((const float *)&in[t][1])[j], ((const float *)&in[t][2])[j] };
+                const float ls[2] = { ((const float *)&in[t][3])[j], ((const float *)&in[t][4])[j] };
+                float c2[2], w2[2], c3[3];
+                decode_pixel_vals(a, o, p0 + j, noc, ls, c2, w2, c3);
+                out[0][j] = c2[0]; out[1][j] = c2[1]; out[2][j] = w2[0]; out[3][j] = w2[1]; out[4][j] = c3[0]; out[5][j] = c3[1]; out[6][j] = c3[2];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                *(float4 *)(a.c2d + ((long long)b * 2 + k) * hw + p0) = make_float4(out[k][0], out[k][1], out[k][2], out[k][3]);
+                *(float4 *)(a.istd + ((long long)b * 2 + k) * hw + p0) = make_float4(out[2 + k][0], out[2 + k][1], out[2 + k][2], out[2 + k][3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *(float4 *)(a.c3d + ((long long)b * 3 + k) * hw + p0) = make_float4(out[4 + k][0], out[4 + k][1], out[4 + k][2], out[4 + k][3]);
+        }
+    }
 }
 
 // numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host:
@@ -399,6 +493,11 @@ __global__ void __launch_bounds__(256) nms_bev_kernel(const float *boxes, const 
     }
 }
 
+__global__ void __launch_bounds__(64) spin_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 #include "kitti_eval_kernel.inc"
 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
@@ -458,10 +557,31 @@ std::atomic<int> g_last_hip_error{0};
 unsigned long long *g_stamps = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
+// What the heuristics below need to know about the device, read once per device from hipGetDeviceProperties (an MI355X reports
+// 256 CUs and 160 KB of LDS per CU; a partitioned or future part reports its own).  CDNA compute units have 4 SIMDs.
+struct DevInfo { int cus; size_t lds_per_cu; };
+DevInfo dev_info() {
+    static std::mutex mu; static DevInfo cache[kMaxDevices]; static bool have[kMaxDevices] = {};
+    int dev = 0;
+    DevInfo d = { 256, (size_t)160 * 1024 };
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return d;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!have[dev]) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+            if (pr.multiProcessorCount > 0) d.cus = pr.multiProcessorCount;
+            if (pr.maxSharedMemoryPerMultiProcessor > 0) d.lds_per_cu = pr.maxSharedMemoryPerMultiProcessor;
+        }
+        cache[dev] = d; have[dev] = true;
+    }
+    return cache[dev];
+}
+constexpr int kSimdsPerCu = 4;
+
 template <typename T, int WPO>
 int launch(const PnpArgs &a, hipStream_t st) {
     const size_t lds = lds_bytes(a, WPO);
-    if (lds > 160 * 1024) return MR_ERR_UNSUPPORTED;
+    if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {
         // the opt-in is a per-device function attribute: remember what was granted on each device
         static std::mutex mu; static size_t granted[kMaxDevices] = {};
@@ -473,7 +593,10 @@ int launch(const PnpArgs &a, hipStream_t st) {
             if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
         }
     }
-    hipLaunchKernelGGL((pnp_uncert_kernel<T, WPO>), dim3(a.B), dim3(64 * WPO), lds, st, a);
+    if (a.flags & MR_ANY_ORDER)      // no barrier bit on the dispatch packet: the launch need not wait for earlier launches on this stream
+        hipExtLaunchKernelGGL((pnp_uncert_kernel<T, WPO>), dim3(a.B), dim3(64 * WPO), (uint32_t)lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a);
+    else
+        hipLaunchKernelGGL((pnp_uncert_kernel<T, WPO>), dim3(a.B), dim3(64 * WPO), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MR_OK;
 }
@@ -500,23 +623,25 @@ int pick_wpo(int B, int P, int flags) {
     if (w) return w;
     // fp32 variants hold 4 resident waves per SIMD (<= 128 VGPRs) -> 4096 waves on 256 CUs x 4 SIMDs.  More waves per
     // object shorten an object's latency chain (what bounds small batches), fewer waves cost fewer instructions per object
-    // (what bounds large ones).  Measured on MI355X, P = 784: 4 waves/object wins up to B = 2048, 2 from B = 4096.
+    // (what bounds large ones).  Measured on MI355X, P = 784: 4 waves/object wins up to B = 2048, 2 from B = 4096
+    // (i.e. while B x waves x 2 does not exceed twice the resident-wave capacity of the chip).
+    const long long wave_slots = (long long)dev_info().cus * kSimdsPerCu * 4;      // 4096 on an MI355X
     w = 1;
-    while (w < 4 && (long long)B * w * 2 <= 8192 && P >= 64 * w * 2) w *= 2;      // small batches: fill the SIMDs
+    while (w < 4 && (long long)B * w * 2 <= 2 * wave_slots && P >= 64 * w * 2) w *= 2;      // small batches: fill the SIMDs
     int wp = 1;
     while (wp < 4 && P > 64 * wp * 8) wp *= 2;                                     // large tiles: <= ~8 points per lane
     if (wp > w) w = wp;                                                            // (P = 784 -> 2, P = 3136 -> 4)
     return w;
 }
 
-// Tiles so large that at most two workgroups fit the 160 KB of a CU (config 5: 56x56 points, 66 KB as fp16, 100 KB as fp32):
+// Tiles so large that at most two workgroups fit the LDS of a CU (config 5: 56x56 points, 66 KB as fp16, 100 KB as fp32 against 160 KB):
 // with 4 waves per object a CU would hold 8 waves; 8 waves per object restore 16 (4 per SIMD — the 128-VGPR kernels allow it).
 // Measured on the config-5 shard (8192 objects, fp16): 0.851 -> 0.810 ms.
 int widen_for_large_tiles(int wpo, const PnpArgs &a, int flags, int in_dtype) {
     if ((flags & MR_WAVES_MASK) || wpo != 4 || in_dtype == MR_F64 || a.P < 64 * 8 * 2) return wpo;
     PnpArgs t = a;
     t.elem_size = (in_dtype == MR_F16) ? 2 : 4;                 // the launcher sets it later, from the template type
-    return (lds_bytes(t, 4) * 3 > (size_t)160 * 1024) ? 8 : wpo;
+    return (lds_bytes(t, 4) * 3 > dev_info().lds_per_cu) ? 8 : wpo;
 }
 
 // 6-DoF refinement (second launch of pnp_uncert(..., use_6dof=True)): see pnp6_kernel.inc
@@ -527,8 +652,19 @@ int launch_pnp6(Pnp6Args &a, hipStream_t st) {
     const int nchunk = (a.P + 63) / 64;
     const size_t lds = sizeof(double) * 2 * 4 * kRedN + sizeof(unsigned long long) * ((nchunk + 3) & ~3) + (size_t)8 * a.P * sizeof(T) +
                        sizeof(uint16_t) * ((a.P + 7) & ~7) + 16;
-    if (lds > 160 * 1024) return MR_ERR_UNSUPPORTED;
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pnp6_refine_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024) {
+        // per-device function attribute, raised monotonically under a lock (two host threads with different P must not shrink it
+        // between the other's set and launch), and no driver call in the steady state — the pattern of launch<T, WPO>
+        static std::mutex mu; static size_t granted[kMaxDevices] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= kMaxDevices || lds > granted[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)pnp6_refine_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
+        }
+    }
     hipLaunchKernelGGL((pnp6_refine_kernel<T>), dim3(a.B), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MR_OK;
@@ -556,6 +692,16 @@ int mr_pnp_last_hip_error(void) { return g_last_hip_error; }
 
 // development aid (not in the public header): device buffer of (B,10) u64 cycle stamps, or NULL to disable
 void mr_pnp_debug_set_stamps(unsigned long long *dev_ptr) { g_stamps = dev_ptr; }
+
+// Occupies one wavefront of the device for `microseconds` (100 MHz constant clock).  PnPPipeline uses it to find out which of
+// its streams the runtime really runs side by side: HIP maps streams onto a small number of hardware queues (4 per priority level
+// by default) and two streams that share a queue serialise.
+int mr_spin(int microseconds, void *stream) {
+    if (microseconds < 0 || microseconds > 1000000) return MR_ERR_BAD_ARGUMENT;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
 
 int mr_pnp_device_count(void) {
     int n = 0;
@@ -702,7 +848,16 @@ int mr_noc_decode_batched(
     a.c2d = coords_2d; a.istd = coords_2d_istd; a.c3d = coords_3d; a.dims = dims; a.dims_var = dims_var;
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     a.map2d = coord_2d_map; a.map_h = map_h; a.map_w = map_w;
-    const long long blocks = (long long)((h * w + 255) / 256) * B;
+    const int hw = h * w;
+    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) &&
+                    ((((uintptr_t)all_pred | (uintptr_t)coords_2d | (uintptr_t)coords_2d_istd | (uintptr_t)coords_3d) & 15) == 0);
+    if (x4) {
+        // 256 threads x one quad measured best (13.5 us per 1024 x 28x28 batch; 128 x 2 quads 15.4, 64 x 4 quads 25.5: the kernel wants threads, not trips)
+        hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4);
+        HIP_TRY(hipGetLastError());
+        return MR_OK;
+    }
+    const long long blocks = (long long)((hw + 255) / 256) * B;
     if (blocks > 0x7fffffffLL) return MR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(noc_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

@@ -109,9 +109,122 @@ class PnPLaunch:
         if self.B == 0:
             return
         st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
-        code = self.lib.mr_pnp_uncert_batched(*self.args, st)
+        if torch.cuda.current_device() != self.dev.index:        # the library launches on the CURRENT HIP device
+            with torch.cuda.device(self.dev):
+                code = self.lib.mr_pnp_uncert_batched(*self.args, st)
+        else:
+            code = self.lib.mr_pnp_uncert_batched(*self.args, st)
         if code:
             _lib.check(code)
+
+
+class PnPPipeline:
+    """Several prepared launches in flight: ``submit`` issues them round-robin on ``depth`` internal HIP streams.
+
+    Why: one launch of B = 1024 objects lasts as long as its slowest object (an object with 17 LM iterations keeps a handful
+    of SIMDs busy for ~50 us while the other 1000 objects finished after ~35 us), and launches on ONE stream serialise, so a
+    single stream pays that tail on every step.  Launches on different streams overlap: the next batches fill the SIMDs the
+    tail leaves idle.  Every launch is still one full fused kernel over its own batch with its own output buffers; results
+    are bit-identical to the single-stream ones (objects are independent; nothing is shared between launches).
+
+        pipe = PnPPipeline(device, depth=4)
+        ev = pipe.submit(launch)            # enqueue; `ev` completes when launch.valid / pose / cov / mask are written
+        torch.cuda.current_stream().wait_event(ev)      # where (and when) a consumer stream needs them
+        pipe.drain()                        # or: host-wait for everything submitted so far
+
+    A launch object owns its output buffers, so the SAME PnPLaunch must not be submitted again before its previous run has
+    completed unless it lands on the same internal stream (``slot`` pins a launch to a stream: give each buffer set a fixed
+    slot and re-submissions are stream-ordered).  ``after`` = an event the inputs depend on (produced on another stream)."""
+
+    def __init__(self, device, depth=4, record_events=True, avoid=(), verify=True):
+        """depth: launches in flight asked for.  HIP maps a process's streams onto a few hardware queues (4 on this stack, the
+        default stream's included) and two streams on one queue serialise — which of torch's pool streams collide is an internal
+        of the runtime (on MI355X / ROCm 7.2 the first four pool streams land on three queues: 23 instead of 34 M solves/s).
+        With verify=True the constructor therefore MEASURES it: candidates are taken from the pool and kept only if a 40 us
+        one-wave spin kernel (mr_spin) on them runs side by side with one on every stream already kept — and on every stream in
+        `avoid` (e.g. the side stream of parallel.RcclAllGather).  ``self.depth`` is the number of streams found (<= depth)."""
+        self.dev = torch.device(device)
+        if self.dev.type != 'cuda':
+            raise RuntimeError('PnPPipeline needs a HIP device (no CPU fallback)')
+        want = max(1, int(depth))
+        self.overlap_test = None
+        if verify and want > 1:
+            self.streams, self.overlap_test = self._pick_streams(want, list(avoid))
+        else:
+            self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(want)]
+        self.depth = len(self.streams)
+        self.handles = [s.cuda_stream for s in self.streams]
+        self.record_events = record_events
+        self._next = 0
+
+    def _pick_streams(self, want, avoid):
+        import time
+        lib = _lib.load()
+        US = 40
+
+        def wall(a, b):
+            best = 1e9
+            for _ in range(3):
+                a.synchronize(); b.synchronize()
+                t0 = time.perf_counter()
+                lib.mr_spin(US, a.cuda_stream)
+                lib.mr_spin(US, b.cuda_stream)
+                a.synchronize(); b.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            return best * 1e6
+        with torch.cuda.device(self.dev):
+            torch.cuda.synchronize(self.dev)
+            first = torch.cuda.Stream(device=self.dev)
+            serial = wall(first, first)                      # two spins on ONE stream: what a collision looks like
+            kept, tested = [first], 0
+            if any(wall(first, a) > serial - 0.5 * US for a in avoid):
+                kept = []
+            for _ in range(8 * want + 8):
+                if len(kept) >= want:
+                    break
+                c = torch.cuda.Stream(device=self.dev)
+                tested += 1
+                if any(c.cuda_stream == k.cuda_stream for k in kept):
+                    continue
+                if all(wall(c, k) < serial - 0.5 * US for k in kept + avoid):      # side by side: about one spin shorter than in series
+                    kept.append(c)
+            if not kept:
+                kept = [first]
+            torch.cuda.synchronize(self.dev)
+        return kept, {'asked': want, 'found': len(kept), 'candidates_tested': tested + 1, 'serial_pair_us': serial}
+
+    def flags_for(self, B, P=784):
+        """The MR_WAVES bits for launches of B objects x P points issued through this pipeline.  The library chooses the number of
+        wavefronts per object from ONE launch's size (4 up to B = 2048, 2 beyond: more waves shorten an object's latency chain,
+        fewer cost fewer instructions per object); with `depth` launches in flight the chip holds depth x B objects, so the same
+        rule is applied to that number (measured on MI355X, 1024-object launches, depth 4: 34 instead of 30 M solves/s)."""
+        eff = int(B) * self.depth
+        w = 1
+        while w < 4 and eff * w * 2 <= 8192 and P >= 64 * w * 2:
+            w *= 2
+        wp = 1
+        while wp < 4 and P > 64 * wp * 8:
+            wp *= 2
+        return max(w, wp) << _lib.MR_WAVES_SHIFT
+
+    def submit(self, launch, slot=None, after=None):
+        k = (self._next if slot is None else int(slot)) % self.depth
+        self._next += 1
+        s = self.streams[k]
+        if after is not None:
+            s.wait_event(after)
+        launch.run(self.handles[k])
+        if not self.record_events:
+            return None
+        ev = getattr(launch, '_done_event', None)
+        if ev is None:                                # created once per launch object (per output-buffer set)
+            ev = launch._done_event = torch.cuda.Event()
+        ev.record(s)
+        return ev
+
+    def drain(self):
+        for s in self.streams:
+            s.synchronize()
 
 
 def pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, inlier_mask_u8, pose4, valid4_u8, z_min=0.5,

@@ -140,7 +140,7 @@ class RcclAllGather:
         # launch instead of beside it: measured 77.9 vs 65.1 us/step at world size 1 (tools/rccl_step_cost.py)
         self.stream = torch.cuda.Stream(device=self.dev, priority=-1)
         self._ready = torch.cuda.Event()
-        self._done = {}          # completion event per send buffer: events are created ONCE (see gather)
+        self._done = {}          # data_ptr -> (send tensor, completion event): events are created ONCE per buffer (see gather)
 
     def _check(self, rc):
         if rc != 0:
@@ -152,20 +152,30 @@ class RcclAllGather:
         self._check(self.lib.ncclCommCount(self.comm, ctypes.byref(n)))
         return int(n.value)
 
-    def gather(self, send, recv):
+    def gather(self, send, recv, after=None):
+        """after: the event that marks `send` complete (e.g. PnPPipeline.submit's return value, when the producer ran on another
+        stream); None = everything enqueued so far on the CURRENT stream."""
         assert send.dtype == torch.uint8 and recv.dtype == torch.uint8 and recv.numel() == self.world * send.numel()
-        self._ready.record(torch.cuda.current_stream(self.dev))
-        self.stream.wait_event(self._ready)
+        if after is None:
+            self._ready.record(torch.cuda.current_stream(self.dev))
+            after = self._ready
+        self.stream.wait_event(after)
         with torch.cuda.device(self.dev):
             self._check(self.lib.ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self.NCCL_UINT8, self.comm,
                                                self.stream.cuda_stream))
         # one completion event per send buffer, re-recorded at every use: creating (and dropping) an event per call costs the
-        # COMPUTE stream ~12 us per step on this stack (tools/rccl_step_cost.py: 77.9 -> 65.1 us/step at world size 1)
-        done = self._done.get(send.data_ptr())
-        if done is None:
-            done = self._done[send.data_ptr()] = torch.cuda.Event()
-        done.record(self.stream)
-        return done
+        # COMPUTE stream ~12 us per step on this stack (tools/rccl_step_cost.py: 77.9 -> 65.1 us/step at world size 1).
+        # The table is keyed by the buffer's address AND holds the tensor, which pins the allocation: the address cannot be
+        # freed and handed to another tensor (which would then inherit a stale event) while its entry exists; `forget` drops it.
+        ent = self._done.get(send.data_ptr())
+        if ent is None or ent[0].numel() != send.numel():
+            ent = self._done[send.data_ptr()] = (send, torch.cuda.Event())
+        ent[1].record(self.stream)
+        return ent[1]
+
+    def forget(self, send):
+        """Drop the completion event (and the reference) kept for a send buffer that will not be used again."""
+        self._done.pop(send.data_ptr(), None)
 
     def close(self):
         if self.comm:

@@ -99,15 +99,23 @@ def _head_output(all_pred, dev):
     return (x if x.is_contiguous() else x.contiguous()), _PRED_DTYPES[x.dtype]
 
 
-def _coord_map_args(coord_2d, dev):
-    """(pointer, H, W) of the optional coord_2d map for the C ABI.  A converted copy may be released as soon as this
-    returns: the caching allocator is stream-ordered and the launch that reads it is the next thing enqueued."""
+def _coord_map(coord_2d, dev):
+    """The optional coord_2d map as the kernels read it: a contiguous fp32 (2,H,W) tensor on `dev` (the input itself when it
+    already is one, otherwise a converted COPY — whoever keeps the pointer beyond one launch must keep this tensor), or None."""
     if coord_2d is None:
-        return None, 0, 0
+        return None
     m = coord_2d.detach().to(device=dev, dtype=torch.float32)
     m = m[0] if m.dim() == 4 else m
     assert m.dim() == 3 and m.shape[0] == 2, 'coord_2d must be (1,2,H,W) or (2,H,W) — one image per call'
-    m = m.contiguous()
+    return m.contiguous()
+
+
+def _coord_map_args(coord_2d, dev):
+    """(pointer, H, W) of the optional coord_2d map for ONE launch that is enqueued right after this returns: a converted copy
+    may then be released at once (the caching allocator is stream-ordered).  A prepared launch must hold `_coord_map`'s tensor."""
+    m = _coord_map(coord_2d, dev)
+    if m is None:
+        return None, 0, 0
     return m.data_ptr(), int(m.shape[1]), int(m.shape[2])
 
 
@@ -177,6 +185,58 @@ def noc_decode(all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_
                 dims_var.data_ptr() if dims_var is not None else None, thr.data_ptr() if thr is not None else None,
                 *_coord_map_args(coord_2d, dev), torch.cuda.current_stream(dev).cuda_stream))
     return dict(coords_2d=c2d, coords_2d_istd=istd, coords_3d=c3d, dims=dims, dims_var=dims_var, ransac_thr=thr)
+
+
+class NocDecodeLaunch:
+    """A PREPARED launch of K2 (``mr_noc_decode_batched``) over static input / output tensors: every ctypes argument is built
+    once, ``run()`` only enqueues the kernel (the eager ``noc_decode`` allocates six outputs and marshals 30 arguments per call —
+    more host time than the ~10 us the kernel takes at B = 1024).  ``out`` has the keys of ``noc_decode``'s result."""
+
+    def __init__(self, all_pred, labels, flip, dim, dim_var, rois, num_classes=3, class_agnostic=False,
+                 dim_means=DIM_MEANS, dim_stds=DIM_STDS, noc_means=NOC_MEANS, noc_stds=NOC_STDS,
+                 ref_length=1.6, ref_focal_y=722, target_std=0.15, epistemic_std_gain=1.0,
+                 std_scale=10, epnp_ransac_thres_ratio=0.2, coord_2d=None):
+        self.lib = _lib.load()
+        dev = all_pred.device
+        if dev.type != 'cuda':
+            raise RuntimeError('NocDecodeLaunch runs on an MI355X only (no CPU fallback)')
+        self.dev = dev
+        B, ch, h, w = all_pred.shape
+        Cn = 1 if class_agnostic else num_classes
+        assert ch == 2 * Cn * 5, f'all_pred has {ch} channels, expected {2 * Cn * 5}'
+        f32 = dict(device=dev, dtype=torch.float32)
+        ap, ap_dt = _head_output(all_pred, dev)
+        r = rois.detach().to(**f32)
+        r = (r[:, 1:5] if r.shape[1] == 5 else r).contiguous()
+        cmap = _coord_map(coord_2d, dev)
+        self.inputs = dict(all_pred=ap, labels=labels.detach().to(device=dev, dtype=torch.int64).contiguous(), flip=_flip_flags(flip, B, dev).clone(),
+                           dim=dim.detach().to(**f32).contiguous(), dim_var=dim_var.detach().to(**f32).contiguous() if dim_var is not None else None,
+                           rois=r, coord_2d=cmap)
+        i = self.inputs
+        mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
+        self._keep = (mu, sd, nm, ns)
+        self.out = dict(coords_2d=torch.empty(B, 2, h, w, **f32), coords_2d_istd=torch.empty(B, 2, h, w, **f32), coords_3d=torch.empty(B, 3, h, w, **f32),
+                        dims=torch.empty(B, 3, **f32), dims_var=torch.empty(B, 3, **f32) if dim_var is not None else None,
+                        ransac_thr=torch.empty(B, **f32) if epnp_ransac_thres_ratio is not None else None)
+        o = self.out
+        self.B = B
+        self.args = [ap.data_ptr(), ap_dt, i['labels'].data_ptr(), i['flip'].data_ptr(), i['dim'].data_ptr(),
+                     i['dim_var'].data_ptr() if i['dim_var'] is not None else None, r.data_ptr(),
+                     B, num_classes, int(class_agnostic), h, w, mu.data_ptr(), sd.data_ptr(), nm.data_ptr(), ns.data_ptr(),
+                     float(ref_length * ref_focal_y * target_std), float(ref_focal_y), float(epistemic_std_gain), float(std_scale),
+                     float(epnp_ransac_thres_ratio) if epnp_ransac_thres_ratio is not None else -1.0,
+                     o['coords_2d'].data_ptr(), o['coords_2d_istd'].data_ptr(), o['coords_3d'].data_ptr(), o['dims'].data_ptr(),
+                     o['dims_var'].data_ptr() if o['dims_var'] is not None else None, o['ransac_thr'].data_ptr() if o['ransac_thr'] is not None else None,
+                     cmap.data_ptr() if cmap is not None else None, int(cmap.shape[1]) if cmap is not None else 0, int(cmap.shape[2]) if cmap is not None else 0]
+
+    def run(self, stream=None):
+        if self.B:
+            with torch.cuda.device(self.dev):
+                st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+                code = self.lib.mr_noc_decode_batched(*self.args, st)
+                if code:
+                    _lib.check(code)
+        return self.out
 
 
 def pnp_from_head(all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shapes, num_classes=3, class_agnostic=False,
@@ -431,8 +491,12 @@ class PoseFromHeadLaunch:
         o['yaw_pred'], o['t_vec_pred'] = o['pose'][:, :1], o['pose'][:, 1:]
         self.logscale = pose_head.cov_calib_logscale.detach().to(**f32).contiguous()
         sdv = ref_length * ref_focal_y * target_std
-        mp, mh, mw = _coord_map_args(coord_2d, dev)
-        self._keep = (ur, vr, mu, sd, nm, ns, coord_2d)
+        # the map as the kernel reads it (a converted copy when coord_2d is fp16 / fp64 / on the host / non-contiguous): the
+        # prepared launch holds it for as long as it lives; `inputs['coord_2d']` may be refreshed in place like the other inputs
+        cmap = _coord_map(coord_2d, dev)
+        self.inputs['coord_2d'] = cmap
+        mp, mh, mw = (cmap.data_ptr(), int(cmap.shape[1]), int(cmap.shape[2])) if cmap is not None else (None, 0, 0)
+        self._keep = (ur, vr, mu, sd, nm, ns, cmap)
         self.B = B
         ratio = pose_head.epnp_ransac_thres_ratio
         self.args = [i['all_pred'].data_ptr(), ap_dt, i['labels'].data_ptr(), i['flip'].data_ptr(), i['dim'].data_ptr(),
@@ -447,25 +511,30 @@ class PoseFromHeadLaunch:
         self.graph = None
 
     def run(self, stream=None):
+        """Enqueue the launch on `stream` (a raw hipStream_t of THIS launch's device) or on that device's current stream.  The
+        library launches on the current HIP device, so the device is made current for the call."""
         if self.B:
-            st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
-            code = self.lib.mr_pnp_from_head_batched(*self.args, st)
-            if code:
-                _lib.check(code)
+            with torch.cuda.device(self.dev):
+                st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+                code = self.lib.mr_pnp_from_head_batched(*self.args, st)
+                if code:
+                    _lib.check(code)
         return self.out
 
     def capture(self):
         """Record the launch into a HIP graph (one warm-up launch first: the LDS opt-in of the kernel is set outside the capture)."""
-        self.run()
-        torch.cuda.synchronize(self.dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.device(self.dev):
             self.run()
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run()
         self.graph = g
         return self
 
     def replay(self):
         if self.graph is None:
             self.capture()
-        self.graph.replay()
+        with torch.cuda.device(self.dev):
+            self.graph.replay()
         return self.out

@@ -357,3 +357,72 @@ def test_fused_path_on_56x56_tiles(dev):
     assert int(r1['ret_val'].sum()) >= 60
     for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'inlier_mask', 'dimensions_pred'):
         assert torch.equal(r1[k], r2[k]), k
+
+
+def test_prepared_launches_keep_a_converted_coord_map_alive(dev):
+    """A coord_2d map that is not already fp32 / contiguous / on the device is CONVERTED for the kernel; a prepared launch reads
+    that copy on every run() / replay(), so it must own it (the copy was released when __init__ returned).  An fp16
+    and a non-contiguous fp64 map must give what the eager call gives, also after other allocations have churned the pool."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head, PoseFromHeadLaunch, NocDecodeLaunch, noc_decode
+    head = UncertPropPnPOptimizer().to(dev)
+    b = syn.make_batch(B=40, seed=11)
+    all_pred, dim = syn.encode_head_outputs(b, seed=11)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    ap, lab, dm, rois, K = t(all_pred), t(b['labels']), t(dim), t(b['rois']), t(b['K'])
+    H, W = 384, 1248
+    ys, xs = np.mgrid[0:H, 0:W]
+    ident = np.stack([xs, ys]).astype(np.float32)
+    maps = {'fp16': t(ident).to(torch.float16),                                   # exact below 2048
+            'fp64 non-contiguous': t(np.stack([xs, ys], -1).astype(np.float64)).permute(2, 0, 1)}
+    for name, m in maps.items():
+        assert name != 'fp64 non-contiguous' or not m.is_contiguous()
+        with torch.no_grad():
+            ref = pose_from_head(head, ap, lab, False, dm, None, rois, K, (syn.IMG_H, syn.IMG_W), coord_2d=m)
+        dref = noc_decode(ap, lab, False, dm, None, rois, coord_2d=m)
+        prepared = PoseFromHeadLaunch(head, ap, lab, False, dm, None, rois, K, (syn.IMG_H, syn.IMG_W), coord_2d=m)
+        k2 = NocDecodeLaunch(ap, lab, False, dm, None, rois, coord_2d=m)
+        junk = [torch.full((2, H, W), float('nan'), device=dev) for _ in range(8)]     # would land on a released copy's memory
+        torch.cuda.synchronize()
+        for _ in range(2):
+            out = prepared.run()
+            dec = k2.run()
+            torch.cuda.synchronize()
+            for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_calib', 'inlier_mask'):
+                assert torch.equal(out[k], ref[k]), (name, k)
+            for k in ('coords_2d', 'coords_2d_istd', 'coords_3d', 'ransac_thr'):
+                assert torch.equal(dec[k], dref[k]), (name, k)
+        del junk
+        assert int(ref['ret_val'].sum()) >= 36
+
+
+def test_pipelined_launches_equal_isolated_launches(dev):
+    """PnPPipeline: prepared launches issued round-robin on internal streams (several batches in flight) write exactly what the
+    same launches write one at a time; the returned events order a consumer stream behind each result."""
+    from monorun_amd import PnPLaunch, PnPPipeline
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    batches = []
+    for seed in (21, 22, 23, 24, 25, 26):
+        b = syn.make_batch(B=256, seed=seed)
+        x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=False)
+        batches.append((t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), t(thr)))
+    mk = lambda a: PnPLaunch(*a[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=a[6], inlier_opt_only=True)
+    ref = [mk(a) for a in batches]
+    for r in ref:
+        r.run()
+    torch.cuda.synchronize()
+    for depth in (1, 3, 4):
+        pipe = PnPPipeline(dev, depth=depth)
+        ls = [mk(a) for a in batches]
+        for rep in range(3):                                   # re-submission of the same launch objects: pinned slots
+            evs = [pipe.submit(l, slot=i) for i, l in enumerate(ls)]
+        consumer = torch.cuda.Stream(device=dev)
+        sums = []
+        with torch.cuda.stream(consumer):
+            for l, ev in zip(ls, evs):
+                consumer.wait_event(ev)
+                sums.append(l.pose.double().sum())
+        consumer.synchronize()
+        pipe.drain()
+        for l, r, sm in zip(ls, ref, sums):
+            assert torch.equal(l.pose, r.pose) and torch.equal(l.cov, r.cov) and torch.equal(l.valid, r.valid) and torch.equal(l.mask, r.mask)
+            assert float(sm) == float(r.pose.double().sum())

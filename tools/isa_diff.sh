@@ -14,7 +14,7 @@ done
 asm() { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I $ROOT/include -S --cuda-device-only $1 -o $2 2>/dev/null; }
 asm $T/old/monorun_pnp.hip $T/old.s
 asm $ROOT/monorun_amd/csrc/monorun_pnp.hip $T/new.s
-body() { awk -v frag="$FRAG" '$0 ~ "^_Z.*" frag ".*:" {on=1} on {print} on && /s_endpgm/ {exit}' $1 | grep -v '^\s*;\|^\.L\|; %bb' | sed 's/;.*//'; }
+body() { awk -v frag="$FRAG" '$0 ~ "^_Z.*" frag ".*:" {on=1} on {print} on && /s_endpgm/ {exit}' $1 | grep -v '^\s*;\|^\.L\|; %bb' | sed 's/;.*//; s/\.LBB[0-9]*_/.LBB_/g'; }      # branch-target labels carry the kernel's ordinal in the file: normalised
 body $T/old.s > $T/old.k; body $T/new.s > $T/new.k
 echo "$(wc -l < $T/old.k) instructions at $REV, $(wc -l < $T/new.k) now, $(diff $T/old.k $T/new.k | grep -c '^[<>]') differing lines"
 rm -rf $T
