@@ -4,6 +4,7 @@ than plain integer #defines, no comments, no extern "C").  INTEGRATION.md §3 ca
 `cffi-cdef` markers; tests/test_capi_and_host.py checks that the two agree and that every prototype is an exported symbol.
 
     python tools/gen_cffi_cdef.py            # prints the cdef text
+    python tools/gen_cffi_cdef.py --update   # rewrites the block in INTEGRATION.md
 """
 import os
 import re
@@ -43,5 +44,17 @@ def cdef_text():
     return '\n'.join(lines) + '\n'
 
 
+def update_integration_md(path=os.path.join(ROOT, 'INTEGRATION.md')):
+    """Rewrite the text between the `cffi-cdef` markers of INTEGRATION.md with the generated prototypes."""
+    src = open(path).read()
+    a, b = src.index('<!-- cffi-cdef:begin -->'), src.index('<!-- cffi-cdef:end -->')
+    head = src[:a] + '<!-- cffi-cdef:begin -->\n```c\n'
+    open(path, 'w').write(head + cdef_text() + '```\n' + src[b:])
+
+
 if __name__ == '__main__':
-    print(cdef_text(), end='')
+    import sys
+    if '--update' in sys.argv:
+        update_integration_md()
+    else:
+        print(cdef_text(), end='')
