@@ -259,6 +259,21 @@ def eig_sym(A):
     return w, vt
 
 
+def eig12(A):
+    """The specification's eigen-solver for the 12 x 12 M^T M (Householder tridiagonalisation + implicit QL, epnp.inc::epnp_eig12):
+    eigenvalues descending, eigenvectors in the rows of vt."""
+    A = _d(A)
+    assert A.shape == (12, 12)
+    w, vt = np.zeros(12), np.zeros((12, 12))
+    lib().orc_eig12(_p(A, c_dp), _p(w, c_dp), _p(vt, c_dp))
+    return w, vt
+
+
+def set_epnp_eig_mode(jacobi):
+    """jacobi=True: EPnP uses the cyclic Jacobi eigen-solver for M^T M (cross-check of the tests); False: the specification (eig12)."""
+    lib().orc_set_epnp_eig_mode(ctypes.c_int(1 if jacobi else 0))
+
+
 def svd_small(A):
     A = _d(A); m, n = A.shape
     w, u, v = np.zeros(n), np.zeros((m, n)), np.zeros((n, n))

@@ -46,6 +46,42 @@ def test_linear_algebra_kernels_against_numpy(orc):
         assert np.all(np.diff(w) <= 0)
 
 
+def test_the_specified_12x12_eigen_solver_against_numpy_and_against_jacobi(orc):
+    """epnp_eig12 (Householder tridiagonalisation + implicit QL: the arithmetic the HIP initialiser follows operation for
+    operation) against numpy on full-rank, rank-10 (five correspondences) and badly scaled M^T M, and EPnP poses computed
+    with it against poses computed with the cyclic Jacobi solver it replaced."""
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        rows = 10 if trial % 3 == 0 else 2 * int(rng.integers(6, 400))
+        m = rng.normal(size=(rows, 12)) * rng.uniform(1e-2, 1e3, 12)
+        s = m.T @ m
+        w, vt = orc.eig12(s)
+        w_np = np.linalg.eigvalsh(s)[::-1]
+        assert np.abs(w - w_np).max() <= 1e-13 * w_np[0]
+        assert np.abs(vt @ vt.T - np.eye(12)).max() <= 1e-13
+        assert np.abs(vt.T @ np.diag(w) @ vt - s).max() <= 1e-13 * w_np[0]
+        assert np.all(np.diff(w) <= 0)
+        if rows == 10:
+            assert np.abs(s @ vt[10:].T).max() <= 1e-11 * w[0]                      # the last two rows span the null space
+    # diagonal and already tridiagonal inputs (reflectors that have nothing to annihilate)
+    d = np.diag(rng.uniform(1, 5, 12)); d[3, 4] = d[4, 3] = 0.7
+    w, vt = orc.eig12(d)
+    assert np.abs(w - np.linalg.eigvalsh(d)[::-1]).max() <= 1e-14 and np.abs(vt.T @ np.diag(w) @ vt - d).max() <= 1e-14
+    w, vt = orc.eig12(np.zeros((12, 12)))
+    assert np.all(w == 0) and np.abs(vt @ vt.T - np.eye(12)).max() == 0
+    # EPnP end to end with either eigen-solver: the same pose on well-posed data
+    X = (rng.uniform(-1, 1, (300, 3)) * np.array([2.0, 0.8, 0.9])).astype(np.float32)
+    R = _rodrigues(np.array([0.05, -0.6, 0.02])); t = np.array([1.2, 1.4, 14.0])
+    x = (_project(X, R, t) + rng.normal(0, 0.3, (300, 2))).astype(np.float32)
+    r_ql, t_ql, _ = orc.epnp(X, x, K)
+    orc.set_epnp_eig_mode(True)
+    try:
+        r_j, t_j, _ = orc.epnp(X, x, K)
+    finally:
+        orc.set_epnp_eig_mode(False)
+    assert np.abs(r_ql - r_j).max() <= 1e-8 and np.abs(t_ql - t_j).max() <= 1e-7
+
+
 def test_cv_rng_is_the_published_multiply_with_carry_generator(orc):
     """cv::RNG: state = (uint32)state * 4164903690 + (state >> 32), next() = (uint32)state, uniform(a,b) = next() % (b-a) + a;
     RANSAC seeds it with (uint64)-1 (ptsetreg.cpp).  Independent Python restatement of the same recurrence."""
