@@ -116,6 +116,42 @@ int mr_pnp_uncert_batched(
     void *stream);
 
 /*
+ * The reference's OWN initialiser on the GPU (pnp_uncert_cpu.py:33-68): for each object, on its istd candidates,
+ *   cv2.solvePnPRansac(X, x, K, 0, reprojectionError=ransac_thr[b], iterationsCount=max_iters (30), flags=SOLVEPNP_EPNP)
+ * — EPnP hypotheses on 5-point subsets drawn by cv::RNG((uint64)-1), float32 squared reprojection error <= thr^2, a model accepted
+ * above max(best, 4) inliers, RANSACUpdateNumIters(0.99, ...), EPnP re-fit on the inliers of the best model — or, with ransac_thr
+ * NULL, plain cv2.solvePnP(..., SOLVEPNP_EPNP) on the candidates (:54-58).  OpenCV is third-party and not part of the reference
+ * tree: the arithmetic is the published algorithm as this repository's test infrastructure restates it.
+ * Inputs as for mr_pnp_uncert_batched (x2d / istd / x3d with element strides, cam_mats (cam_batch,3,3), istd_thres, the
+ * MR_MEAN_* / MR_NO_ISTD_MASK flags).  Outputs (device): init_pose (B,4) f64 [yaw0 = r_vec[1], tx, ty, tz] (:68; zeros on
+ * failure), init_mask (B,P) u8 = the istd candidates narrowed to the RANSAC inliers (:43-51), init_valid (B) u8 (0: RANSAC found no
+ * model with 5 inliers, or the pose is not finite — the reference then returns (False, 0, 0, I, 0, mask), :119-125),
+ * diag (B,4) f32 or NULL [RANSAC iterations run, inliers of the best model, candidates, index of the best model],
+ * debug_hypotheses (B,30,12) f64 or NULL (every hypothesis' R | t; tests).  Feed the three outputs to
+ * mr_pnp_uncert_from_init_batched for the LM + covariance.
+ */
+int mr_epnp_ransac_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *ransac_thr, int B, int P,
+    float istd_thres, int flags, int max_iters,
+    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses, void *stream);
+
+/*
+ * LM + covariance (stages 3 and 4 of mr_pnp_uncert_batched) from an EXTERNAL initialiser's result: init_mask (B,P) u8 is the
+ * candidate = inlier set the LM sees (inlier_opt_only) and the mask the covariance uses, init_pose (B,4) f64 the start, init_valid
+ * (B) u8 = 0 marks objects whose initialiser failed (valid = 0, zero pose, as pnp_uncert_cpu.py:119-125).  Everything else as
+ * for mr_pnp_uncert_batched; inlier_mask (B,P) receives init_mask.
+ */
+int mr_pnp_uncert_from_init_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const double *init_pose, const uint8_t *init_mask, const uint8_t *init_valid, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream);
+
+/*
  * True 6-DoF refinement (the flag the reference declares and ignores: `use_6dof`, pnp_uncert.py:11).
  * Second launch of pnp_uncert(..., use_6dof=True): for each object, starting from the 4-DoF result pose4 = [yaw,tx,ty,tz]
  * (r = (0,yaw,0)) on the points of that solve's final inlier_mask, the same residual functor (pnp_uncert_cpu.cpp:24-51) is

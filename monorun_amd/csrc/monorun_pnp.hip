@@ -367,12 +367,14 @@ struct PnpArgs {
     int from_head;                            // 1: the tile is decoded in-kernel from the raw NOC-head output (`dec`)
     DecodeArgs dec;
     PairwisePlan plan;
+    const uint8_t *init_mask, *init_valid;    // EXT launches only (appended: the offsets of everything above are what the tuned kernels read)
 };
 
 #include "pnp_kernel.inc"
 #include "pnp6_kernel.inc"
 #include "hessian_kernel.inc"
 #include "pnp_noc_kernel.inc"
+#include "epnp_kernel.inc"
 constexpr size_t kNocLds = sizeof(double) * (2 * 4 * kRedN + 2 * 40);     // reduction scratch + two sets of block sums
 
 // ------------------------------------------------------------------------------------------------
@@ -601,6 +603,25 @@ int launch(const PnpArgs &a, hipStream_t st) {
     return MR_OK;
 }
 
+template <typename T, int WPO>
+int launch_ext(const PnpArgs &a, hipStream_t st) {
+    const size_t lds = lds_bytes(a, WPO);
+    if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024) {
+        static std::mutex mu; static size_t granted[kMaxDevices] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= kMaxDevices || lds > granted[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)pnp_uncert_kernel<T, WPO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
+        }
+    }
+    hipLaunchKernelGGL((pnp_uncert_kernel<T, WPO, true>), dim3(a.B), dim3(64 * WPO), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
 template <typename T>
 int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
     a.elem_size = (int)sizeof(T);
@@ -608,6 +629,16 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
     a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
     { const int mi = (a.flags & MR_LM_MAXIT_MASK) >> MR_LM_MAXIT_SHIFT; a.lm_max_iter = mi ? mi : 50; }
+    if (a.init_mask) {                      // external initialiser: 2, 4 or 8 waves per object
+        if (wpo < 2) wpo = 2;
+        if (wpo == 3) wpo = 4;
+        switch (wpo) {
+            case 2: return launch_ext<T, 2>(a, st);
+            case 4: return launch_ext<T, 4>(a, st);
+            case 8: return launch_ext<T, 8>(a, st);
+            default: return MR_ERR_BAD_ARGUMENT;
+        }
+    }
     switch (wpo) {
         case 1: return launch<T, 1>(a, st);
         case 2: return launch<T, 2>(a, st);
@@ -670,6 +701,30 @@ int launch_pnp6(Pnp6Args &a, hipStream_t st) {
     return MR_OK;
 }
 
+template <typename T>
+int launch_epnp(EpnpArgs &ea, hipStream_t st) {
+    PnpArgs &a = ea.p;
+    a.elem_size = (int)sizeof(T);
+    a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
+    a.nca = (((a.P + 63) / 64) + 3) & ~3;
+    a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
+    const size_t lds = epnp_lds_bytes(a);
+    if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
+    {
+        static std::mutex mu; static size_t granted[kMaxDevices] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= kMaxDevices || lds > granted[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)epnp_ransac_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
+        }
+    }
+    hipLaunchKernelGGL((epnp_ransac_kernel<T>), dim3(a.B), dim3(kEpThreads), lds, st, ea);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
 }  // namespace
 
 // ================================================================================= C ABI =========
@@ -709,11 +764,11 @@ int mr_pnp_device_count(void) {
     return n;
 }
 
-int mr_pnp_uncert_batched(
+static int pnp_uncert_launch(
     const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
     const void *x3d, const int64_t *x3d_strides, int in_dtype,
     const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
-    const float *ransac_thr, const double *init_pose, int B, int P,
+    const float *ransac_thr, const double *init_pose, const uint8_t *init_mask, const uint8_t *init_valid, int B, int P,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream) {
     if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
@@ -728,14 +783,14 @@ int mr_pnp_uncert_batched(
     for (int i = 0; i < 3; ++i) { a.s2[i] = x2d_strides[i]; a.sw[i] = istd_strides[i]; a.s3[i] = x3d_strides[i]; }
     a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
     a.ur = u_range; a.vr = v_range; a.r_stride = (range_batch == 1) ? 0 : 2; a.r_f64 = 0;
-    a.ransac_thr = ransac_thr; a.init_pose = init_pose;
+    a.ransac_thr = ransac_thr; a.init_pose = init_pose; a.init_mask = init_mask; a.init_valid = init_valid;
     a.B = B; a.P = P; a.z_min = (double)z_min; a.istd_thres = istd_thres; a.inlier_opt_only = inlier_opt_only; a.flags = flags;
     a.valid = valid; a.pose = pose; a.cov = cov; a.tr = tr_radius; a.mask = inlier_mask; a.diag = diag;
     a.stamps = g_stamps;
     int mm = flags & MR_MEAN_MASK;
     if (mm == MR_MEAN_AUTO) mm = (istd_strides[1] == 1 && P > 1) ? MR_MEAN_PAIRWISE : MR_MEAN_SEQUENTIAL;
     a.mean_mode = mm;
-    if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
+    if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK) && !init_mask) {
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
     const int wpo = widen_for_large_tiles(pick_wpo(B, P, flags), a, flags, in_dtype);
@@ -744,6 +799,67 @@ int mr_pnp_uncert_batched(
         case MR_F32: return launch_wpo<float>(a, wpo, st);
         case MR_F16: return launch_wpo<__half>(a, wpo, st);
         case MR_F64: return launch_wpo<double>(a, wpo, st);
+        default: return MR_ERR_UNSUPPORTED;
+    }
+}
+
+int mr_pnp_uncert_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const float *ransac_thr, const double *init_pose, int B, int P,
+    float z_min, float istd_thres, int inlier_opt_only, int flags,
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream) {
+    return pnp_uncert_launch(x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, u_range, v_range, range_batch,
+                             ransac_thr, init_pose, nullptr, nullptr, B, P, z_min, istd_thres, inlier_opt_only, flags,
+                             valid, pose, cov, tr_radius, inlier_mask, diag, stream);
+}
+
+int mr_pnp_uncert_from_init_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
+    const double *init_pose, const uint8_t *init_mask, const uint8_t *init_valid, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream) {
+    if (B > 0 && (!init_pose || !init_mask || !init_valid)) return MR_ERR_BAD_ARGUMENT;
+    return pnp_uncert_launch(x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, u_range, v_range, range_batch,
+                             nullptr, init_pose, init_mask, init_valid, B, P, z_min, 0.0f, inlier_opt_only, flags,
+                             valid, pose, cov, tr_radius, inlier_mask, diag, stream);
+}
+
+int mr_epnp_ransac_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *ransac_thr, int B, int P,
+    float istd_thres, int flags, int max_iters,
+    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses, void *stream) {
+    if (B < 0 || P < 4 || P > 64 * kMaxChunks || max_iters < 1 || max_iters > kEpMaxIters) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !init_pose || !init_mask || !init_valid)
+        return MR_ERR_BAD_ARGUMENT;
+    if (cam_batch != 1 && cam_batch != B) return MR_ERR_BAD_ARGUMENT;
+    EpnpArgs ea;
+    memset(&ea, 0, sizeof ea);
+    PnpArgs &a = ea.p;
+    a.x2d = x2d; a.istd = istd; a.x3d = x3d;
+    for (int i = 0; i < 3; ++i) { a.s2[i] = x2d_strides[i]; a.sw[i] = istd_strides[i]; a.s3[i] = x3d_strides[i]; }
+    a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
+    a.ransac_thr = ransac_thr;
+    a.B = B; a.P = P; a.istd_thres = istd_thres; a.flags = flags;
+    int mm = flags & MR_MEAN_MASK;
+    if (mm == MR_MEAN_AUTO) mm = (istd_strides[1] == 1 && P > 1) ? MR_MEAN_PAIRWISE : MR_MEAN_SEQUENTIAL;
+    a.mean_mode = mm;
+    if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
+        if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
+    }
+    ea.init_pose = init_pose; ea.init_mask = init_mask; ea.init_ok = init_valid; ea.diag = diag; ea.dbg_hyp = debug_hypotheses;
+    ea.max_iters = max_iters;
+    hipStream_t st = (hipStream_t)stream;
+    switch (in_dtype) {
+        case MR_F32: return launch_epnp<float>(ea, st);
+        case MR_F16: return launch_epnp<__half>(ea, st);
+        case MR_F64: return launch_epnp<double>(ea, st);
         default: return MR_ERR_UNSUPPORTED;
     }
 }

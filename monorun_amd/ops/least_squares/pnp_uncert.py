@@ -65,6 +65,71 @@ def pnp_uncert_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v
     return valid, pose, cov, tr, mask, diag
 
 
+def epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd_thres=1.0, epnp_ransac_thres=None, flags=0,
+                       max_iters=30, with_diag=False, debug_hypotheses=False):
+    """The reference's own initialiser on the GPU (``mr_epnp_ransac_batched``): cv2.solvePnPRansac(..., iterationsCount=30,
+    flags=SOLVEPNP_EPNP) on the istd candidates of every object (plain EPnP without thresholds), pnp_uncert_cpu.py:33-68.
+    Returns (init_pose f64 (B,4) [yaw0, t], init_mask u8 (B,P), init_valid u8 (B,), diag f32 (B,4)|None, hypotheses f64 (B,30,12)|None)."""
+    lib = _lib.load()
+    dev = coords_2d.device
+    if dev.type != 'cuda':
+        raise RuntimeError('monorun_amd EPnP/RANSAC runs on an MI355X only (no CPU fallback)')
+    B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+    dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
+    prep = lambda t: t.detach() if (t.dtype == dt and t.device == dev) else t.detach().to(device=dev, dtype=dt)
+    x2d, istd, x3d = prep(coords_2d), prep(coords_2d_istd), prep(coords_3d)
+    f32 = dict(device=dev, dtype=torch.float32)
+    cam = cam_mats.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    thr = epnp_ransac_thres.detach().to(**f32).reshape(-1).contiguous() if epnp_ransac_thres is not None else None
+    init_pose = torch.empty(B, 4, device=dev, dtype=torch.float64)
+    init_mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    init_valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    diag = torch.empty(B, 4, **f32) if with_diag else None
+    hyp = torch.zeros(B, 30, 12, device=dev, dtype=torch.float64) if debug_hypotheses else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_epnp_ransac_batched(
+                x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt],
+                cam.data_ptr(), cam.shape[0], thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), int(flags), int(max_iters),
+                init_pose.data_ptr(), init_mask.data_ptr(), init_valid.data_ptr(), diag.data_ptr() if diag is not None else None,
+                hyp.data_ptr() if hyp is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+    return init_pose, init_mask, init_valid, diag, hyp
+
+
+def pnp_uncert_from_init_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, init_pose, init_mask, init_valid,
+                                z_min=0.5, inlier_opt_only=False, flags=0, with_diag=False):
+    """LM + covariance from an external initialiser's (init_pose f64 (B,4), init_mask u8 (B,P), init_valid u8 (B,))
+    (``mr_pnp_uncert_from_init_batched``).  Returns what ``pnp_uncert_device`` returns."""
+    lib = _lib.load()
+    dev = coords_2d.device
+    B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+    dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
+    prep = lambda t: t.detach() if (t.dtype == dt and t.device == dev) else t.detach().to(device=dev, dtype=dt)
+    x2d, istd, x3d = prep(coords_2d), prep(coords_2d_istd), prep(coords_3d)
+    f32 = dict(device=dev, dtype=torch.float32)
+    cam = cam_mats.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    ur = u_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    vr = v_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    ini = init_pose.detach().to(device=dev, dtype=torch.float64).reshape(-1, 4).contiguous()
+    im = init_mask.detach().to(device=dev, dtype=torch.uint8).contiguous()
+    iv = init_valid.detach().to(device=dev, dtype=torch.uint8).contiguous()
+    valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    pose = torch.empty(B, 4, **f32)
+    cov = torch.empty(B, 4, 4, **f32)
+    tr = torch.empty(B, **f32)
+    mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    diag = torch.empty(B, 4, **f32) if with_diag else None
+    if B > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.mr_pnp_uncert_from_init_batched(
+                x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt],
+                cam.data_ptr(), cam.shape[0], ur.data_ptr(), vr.data_ptr(), ur.shape[0],
+                ini.data_ptr(), im.data_ptr(), iv.data_ptr(), B, P, float(z_min), int(bool(inlier_opt_only)), int(flags),
+                valid.data_ptr(), pose.data_ptr(), cov.data_ptr(), tr.data_ptr(), mask.data_ptr(),
+                diag.data_ptr() if diag is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+    return valid, pose, cov, tr, mask, diag
+
+
 class PnPLaunch:
     """A prepared launch of the fused kernel over device-resident inputs with preallocated outputs:
     every ctypes argument is built once, ``run()`` only enqueues the kernel on the current stream.
@@ -287,7 +352,7 @@ def exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range
 
 
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
-               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False):
+               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser='k0'):
     """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
 
     coords_2d / coords_2d_istd (B,P,2), coords_3d (B,P,3), cam_mats (B|1,3,3), u_range / v_range (B|1,2),
@@ -296,6 +361,10 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     longer runs on torch >= 2): pose_cov = inverse of the exact Hessian of the masked cost (hessian.py:5-64) instead of
     inverse(J^T J) — a second launch (exact_hessian_device); ignored together with use_6dof=True (the 6-DoF covariance is the
     solver's J^T J).
+    initialiser (not a reference keyword): 'k0' = this repository's deterministic consensus initialiser inside the fused kernel (one
+    launch); 'epnp' = the reference's own initialiser — cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP),
+    pnp_uncert_cpu.py:33-68 — as its own launch in front of the LM (two launches; the published algorithm as DESIGN.md §5 restates
+    it: inlier sets, start pose and hence the returned pose are then the reference flow's, up to what OpenCV's own build would do).
     use_6dof=False (every shipped config): returns (ret_val (B,) bool, r_vec (B,1) yaw, t_vec (B,3), pose_cov (B,4,4) covariance of
     [yaw, t], inlier_mask (B,P) bool) on the device and in the dtype of coords_2d — the reference's tuple.
     use_6dof=True: the flag the reference declares and never reads (pnp_uncert.py:11) made real — after the 4-DoF solve (mask,
@@ -312,9 +381,17 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
             dev = torch.device('cuda', torch.cuda.current_device())
             mv = lambda t: t.to(dev) if t is not None else None
             coords_2d, coords_2d_istd, coords_3d = mv(coords_2d), mv(coords_2d_istd), mv(coords_3d)
-        valid, pose, cov, _, mask, _ = pnp_uncert_device(
-            coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=z_min,
-            epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres, inlier_opt_only=inlier_opt_only)
+        if initialiser == 'epnp':
+            ini, imask, ivalid, _, _ = epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd_thres=epnp_istd_thres,
+                                                          epnp_ransac_thres=epnp_ransac_thres)
+            valid, pose, cov, _, mask, _ = pnp_uncert_from_init_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
+                                                                       ini, imask, ivalid, z_min=z_min, inlier_opt_only=inlier_opt_only)
+        elif initialiser == 'k0':
+            valid, pose, cov, _, mask, _ = pnp_uncert_device(
+                coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=z_min,
+                epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres, inlier_opt_only=inlier_opt_only)
+        else:
+            raise ValueError(f"initialiser must be 'k0' or 'epnp', got {initialiser!r}")
         odt = coords_2d.dtype
         if use_6dof:
             valid6, pose6, cov6, _ = pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, mask, pose, valid, z_min=z_min)
@@ -334,12 +411,15 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
 class PnPUncert(torch.nn.Module):
 
     def __init__(self, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, coord_istd_normalize=False,
-                 forward_exact_hessian=False, use_6dof=False, eps=1e-6):
+                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser='k0'):
         """Module form (constructor keywords of the reference, pnp_uncert.py:93-99; no parameters, no buffers).
         epnp_istd_thres: a point is an istd inlier when both of its istd components reach this factor times the object's
         mean; inlier_opt_only: the LM refines on the inlier set only; coord_istd_normalize: divide the istd map by its
-        per-object mean (clamped at eps) first."""
+        per-object mean (clamped at eps) first.  initialiser ('k0' | 'epnp', not a reference keyword): see ``pnp_uncert``."""
         super().__init__()
+        if initialiser not in ('k0', 'epnp'):
+            raise ValueError(f"initialiser must be 'k0' or 'epnp', got {initialiser!r}")
+        self.initialiser = initialiser
         self.z_min, self.epnp_istd_thres, self.inlier_opt_only = z_min, epnp_istd_thres, inlier_opt_only
         self.coord_istd_normalize, self.eps = coord_istd_normalize, eps
         self.forward_exact_hessian, self.use_6dof = forward_exact_hessian, use_6dof
@@ -351,4 +431,4 @@ class PnPUncert(torch.nn.Module):
         return pnp_uncert(coords_2d, istd, coords_3d, cam_mats, u_range, v_range, z_min=self.z_min,
                           epnp_istd_thres=self.epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres,
                           inlier_opt_only=self.inlier_opt_only, forward_exact_hessian=self.forward_exact_hessian,
-                          use_6dof=self.use_6dof)
+                          use_6dof=self.use_6dof, initialiser=self.initialiser)

@@ -49,6 +49,7 @@ def lib():
         _LIB.orc_k0_init.restype = ctypes.c_int
         _LIB.orc_pose_cov.restype = ctypes.c_int
         _LIB.orc_epnp_ransac.restype = ctypes.c_int
+        _LIB.orc_epnp_ransac_trace.restype = ctypes.c_int
     return _LIB
 
 
@@ -250,6 +251,19 @@ def epnp_ransac(obj, img, K, thr, max_iters=30):
     ok = lib().orc_epnp_ransac(_p(obj, c_fp), _p(img, c_fp), ctypes.c_int(obj.shape[0]), _p(K, c_fp), ctypes.c_float(thr), ctypes.c_int(max_iters),
                                _p(rvec, c_dp), _p(tvec, c_dp), _p(mask, c_u8p), _p(it, c_ip))
     return dict(ok=bool(ok), rvec=rvec, tvec=tvec, mask=mask.astype(bool), iters=int(it[0]))
+
+
+def epnp_ransac_trace(obj, img, K, thr, max_iters=30):
+    """epnp_ransac plus, for every RANSAC iteration that ran, the hypothesis (R after the Rodrigues round trip | t, (max_iters,12)) and
+    its inlier count ((max_iters,), -1 = not evaluated because the adaptive iteration count had already been reached)."""
+    obj, img, K = _f(obj), _f(img), _f(K).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    mask = np.zeros(obj.shape[0], np.uint8)
+    it = np.zeros(1, np.int32)
+    hyp, cnt = np.zeros((max_iters, 12)), np.zeros(max_iters, np.int32)
+    ok = lib().orc_epnp_ransac_trace(_p(obj, c_fp), _p(img, c_fp), ctypes.c_int(obj.shape[0]), _p(K, c_fp), ctypes.c_float(thr), ctypes.c_int(max_iters),
+                                     _p(rvec, c_dp), _p(tvec, c_dp), _p(mask, c_u8p), _p(it, c_ip), _p(hyp, c_dp), _p(cnt, c_ip))
+    return dict(ok=bool(ok), rvec=rvec, tvec=tvec, mask=mask.astype(bool), iters=int(it[0]), hyp=hyp, cnt=cnt)
 
 
 def eig_sym(A):
