@@ -708,7 +708,9 @@ int launch_epnp(EpnpArgs &ea, hipStream_t st) {
     a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
     a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
-    const size_t lds = epnp_lds_bytes(a);
+    size_t lds = epnp_lds_bytes(a, false);
+    ea.alias_ws = 0;
+    if (lds > dev_info().lds_per_cu) { ea.alias_ws = 1; lds = epnp_lds_bytes(a, true); }      // large tiles: workspaces overlay the records
     if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
     {
         static std::mutex mu; static size_t granted[kMaxDevices] = {};

@@ -51,3 +51,14 @@ torch.cuda.synchronize()
 valid, pose, mask = valid.cpu().numpy().astype(bool), pose.cpu().numpy(), mask.cpu().numpy().astype(bool)
 print('end to end: valid equal', np.array_equal(valid, ref[0]), 'mask equal', np.array_equal(mask, ref[5]),
       'yaw', np.abs(np.angle(np.exp(1j * (pose[:, :1] - ref[1]))))[ref[0]].max(), 't', np.abs(pose[:, 1:] - ref[2])[ref[0]].max())
+# timing: the initialiser launch and the LM launch behind it
+e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+dx = [t(a) for a in (x2d, istd, x3d, K, ur, vr, thr)]
+for rep in range(3):
+    e[0].record()
+    ini_t, im_t, iv_t, _, _ = epnp_ransac_device(dx[0], dx[1], dx[2], dx[3], epnp_istd_thres=0.6, epnp_ransac_thres=dx[6])
+    e[1].record()
+    pnp_uncert_from_init_device(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5], ini_t, im_t, iv_t, z_min=0.5, inlier_opt_only=True)
+    e[2].record()
+    torch.cuda.synchronize()
+    print(f'B = {B}: EPnP/RANSAC launch {e[0].elapsed_time(e[1]) * 1e3:.0f} us, LM launch {e[1].elapsed_time(e[2]) * 1e3:.0f} us')

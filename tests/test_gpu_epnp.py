@@ -1,0 +1,201 @@
+"""R5 on the GPU: the reference's own initialiser — cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP) inside the
+per-object driver, /root/reference/monorun/ops/least_squares/pnp_uncert_cpu.py:33-68 — as `mr_epnp_ransac_batched`, against the
+CPU restatement (oracle/epnp.inc; OpenCV itself is third-party and absent: "parity unpinned" against a cv2 binary, pinned against
+the restatement's known answers in tests/test_oracle_epnp.py).  Bars: RANSAC masks BIT-EXACT, initial pose
+<= 1e-9, pose after the LM <= 1e-4 with identical LM iteration counts and exit reasons."""
+import numpy as np
+import pytest
+import torch
+
+from monorun_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+INIT_TOL = 1e-9          # the arithmetic is the restatement's operation for operation; what differs is acos / sin / cos (ulps)
+POSE_TOL = 1e-4          # north_star: rotation / translation within 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def _t(dev, a):
+    t = torch.from_numpy(np.asarray(a))
+    d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev)
+    d.copy_(t)
+    return d
+
+
+def _stage_reference(orc, x2d, istd, x3d, K, thr, istd_thres=0.6):
+    """per object: candidates (pnp_uncert_cpu.py:164-168, :23-32) -> the restated solvePnPRansac with a trace of its hypotheses"""
+    cand = orc.istd_inlier_mask(istd, np.float32(istd_thres))
+    out = []
+    for i in range(x2d.shape[0]):
+        m = cand[i] if cand[i].sum() > 4 else np.ones_like(cand[i])
+        idx = np.nonzero(m)[0]
+        Ki = K.reshape(-1, 9)[i if K.reshape(-1, 9).shape[0] > 1 else 0]
+        r = orc.epnp_ransac_trace(x3d[i][idx], x2d[i][idx], Ki, float(thr[i]))
+        full = np.zeros_like(m)
+        if r['ok']:
+            full[idx] = r['mask']
+        else:
+            full = m.copy()
+        r['full_mask'] = full
+        r['n'] = len(idx)
+        out.append(r)
+    return out
+
+
+def _check_stage(gpu, refs):
+    ini, imask, ivalid, diag, hyp = [a.cpu().numpy() for a in gpu]
+    worst_init = 0.0
+    for i, r in enumerate(refs):
+        ev = r['cnt'] >= 0                                # the iterations the sequential loop really ran
+        a, c = hyp[i][ev], r['hyp'][ev]
+        both_nan = np.isnan(a) & np.isnan(c)
+        assert np.all(both_nan | (np.abs(a - c) <= 1e-12 * np.maximum(1.0, np.abs(c)))), (i, 'hypotheses')
+        assert np.array_equal(imask[i].astype(bool), r['full_mask']), (i, 'RANSAC inlier mask')
+        assert bool(ivalid[i]) == r['ok'], (i, 'success flag')
+        assert int(diag[i, 0]) == r['iters'] and int(diag[i, 2]) == r['n'], (i, 'iterations / candidates')
+        if r['ok']:
+            assert int(diag[i, 1]) == int(r['mask'].sum()), (i, 'inlier count of the best model')
+            ref = np.array([r['rvec'][1], *r['tvec']])
+            worst_init = max(worst_init, np.abs(ref - ini[i]).max())
+        else:
+            assert np.all(ini[i] == 0.0)
+    assert worst_init <= INIT_TOL, worst_init
+    return worst_init
+
+
+@pytest.mark.parametrize('planar', [True, False])
+def test_ransac_stage_object_by_object(dev, orc, planar):
+    """config-2 objects, both layouts (numpy's pairwise vs sequential istd mean decides the candidates): every hypothesis the
+    sequential RANSAC evaluated, its iteration count, the inlier mask (bit-exact), the success flag and the initial pose."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    b = syn.make_batch(B=160, seed=1234)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=planar)
+    gpu = epnp_ransac_device(_t(dev, x2d), _t(dev, istd), _t(dev, x3d), _t(dev, K), epnp_istd_thres=0.6, epnp_ransac_thres=_t(dev, thr),
+                             with_diag=True, debug_hypotheses=True)
+    torch.cuda.synchronize()
+    refs = _stage_reference(orc, np.ascontiguousarray(x2d), np.ascontiguousarray(istd), np.ascontiguousarray(x3d), K, thr)
+    _check_stage(gpu, refs)
+    assert sum(r['ok'] for r in refs) >= 155 and max(r['iters'] for r in refs) > 3      # the adaptive iteration count is exercised
+
+
+def test_hard_objects_many_iterations_failures_and_tiny_sets(dev, orc):
+    """heavy outlier shares (the adaptive count stays high: up to 30 iterations replayed), a threshold so small that no model
+    reaches 5 inliers (failure: flag 0, zero pose, mask = the istd candidates), exactly 5 candidates (solved directly, all
+    inliers), fewer than 5 (failure), per-object cameras."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    rng = np.random.default_rng(5)
+    b = syn.make_batch(B=48, seed=77)
+    x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+    x2d, x3d, thr, istd = x2d.copy(), x3d.copy(), thr.copy(), istd.copy()
+    P = x2d.shape[1]
+    for i in range(0, 16):                                 # 40 - 70 % gross outliers among the candidates
+        bad = rng.random(P) < rng.uniform(0.4, 0.7)
+        x3d[i, bad] += rng.normal(0, 0.8, (int(bad.sum()), 3)).astype(np.float32)
+    thr[16:20] = 1e-4                                      # nothing fits: RANSAC fails
+    for i in range(20, 24):                                # exactly five candidates
+        istd[i] = 1e-3; istd[i, rng.choice(P, 5, replace=False)] = 1.0
+    Kb = np.repeat(K.reshape(1, 3, 3), 48, 0).copy(); Kb[:, 0, 0] *= np.linspace(0.97, 1.03, 48).astype(np.float32); Kb[:, 1, 2] += np.linspace(-4, 4, 48).astype(np.float32)
+    gpu = epnp_ransac_device(_t(dev, x2d), _t(dev, istd), _t(dev, x3d), _t(dev, Kb), epnp_istd_thres=0.6, epnp_ransac_thres=_t(dev, thr),
+                             with_diag=True, debug_hypotheses=True)
+    torch.cuda.synchronize()
+    refs = _stage_reference(orc, x2d, istd, x3d, Kb, thr)
+    _check_stage(gpu, refs)
+    assert max(r['iters'] for r in refs[:16]) >= 20 and not any(r['ok'] for r in refs[16:20]) and all(r['n'] == 5 and r['ok'] for r in refs[20:24])
+    # four points only (P = 4): fewer than the five a sample needs -> failure for every object, mask = all points
+    g4 = epnp_ransac_device(_t(dev, x2d[:8, :4]), _t(dev, istd[:8, :4]), _t(dev, x3d[:8, :4]), _t(dev, K), epnp_istd_thres=0.6,
+                            epnp_ransac_thres=_t(dev, thr[:8]), with_diag=True)
+    torch.cuda.synchronize()
+    assert not g4[2].any() and bool((g4[0] == 0).all()) and bool((g4[1] == 1).all())
+
+
+def test_plain_epnp_without_thresholds(dev, orc):
+    """epnp_ransac_thres=None: cv2.solvePnP(..., SOLVEPNP_EPNP) on the candidates (pnp_uncert_cpu.py:54-58) — the cooperative EPnP
+    alone, on 5 ... 784 points."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    b = syn.make_batch(B=40, seed=31)
+    x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+    istd = istd.copy()
+    rng = np.random.default_rng(9)
+    for i, k in enumerate((5, 6, 7, 9, 33, 64, 65, 127, 128, 129, 300)):          # k candidates (ragged sets around the 64-lane partials)
+        istd[i] = 1e-3; istd[i, rng.choice(x2d.shape[1], k, replace=False)] = 1.0
+    ini, imask, ivalid, _, _ = epnp_ransac_device(_t(dev, x2d), _t(dev, istd), _t(dev, x3d), _t(dev, K), epnp_istd_thres=0.6)
+    torch.cuda.synchronize()
+    ini, imask, ivalid = ini.cpu().numpy(), imask.cpu().numpy().astype(bool), ivalid.cpu().numpy().astype(bool)
+    cand = orc.istd_inlier_mask(istd, np.float32(0.6))
+    for i in range(40):
+        m = cand[i] if cand[i].sum() > 4 else np.ones_like(cand[i])
+        rvec, tvec, _ = orc.epnp(x3d[i][m], x2d[i][m], K)
+        assert np.array_equal(imask[i], m) and ivalid[i]
+        assert np.abs(np.array([rvec[1], *tvec]) - ini[i]).max() <= INIT_TOL, i
+
+
+def test_end_to_end_config2_1024_objects(dev, orc):
+    """pnp_uncert(..., initialiser='epnp') — two launches: EPnP/RANSAC, then the LM + covariance from its result — against the
+    reference's flow restated (u2d_pnp_epnp): 1024 config-2 objects, masks bit-exact, identical LM iteration counts and exit
+    reasons, pose within 1e-4, covariance within 1e-5 relative."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+    from monorun_amd.ops import build_pnp
+    b = syn.make_batch(B=1024, seed=1234)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_init=True, num_threads=0)
+    d = [_t(dev, a) for a in (x2d, istd, x3d, K, ur, vr, thr)]
+    ini, imask, ivalid, _, _ = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[6])
+    valid, pose, cov, tr, mask, diag = [a.cpu().numpy() for a in pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, imask, ivalid, z_min=0.5,
+                                                                                           inlier_opt_only=True, with_diag=True)]
+    r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag, r_init = ref
+    assert np.array_equal(mask.astype(bool), r_mask) and np.array_equal(valid.astype(bool), r_ret)
+    assert np.abs(ini.cpu().numpy() - r_init).max() <= INIT_TOL
+    assert np.array_equal(diag[:, 0], r_diag[:, 0]) and np.array_equal(diag[:, 2], r_diag[:, 2]), 'LM iteration counts / exit reasons'
+    ok = r_ret
+    dyaw = np.abs(np.angle(np.exp(1j * (pose[:, 0] - r_yaw[:, 0]))))
+    assert dyaw[ok].max() <= POSE_TOL and np.abs(pose[:, 1:] - r_t)[ok].max() <= POSE_TOL
+    scale = np.abs(r_cov[ok]).reshape(ok.sum(), -1).max(1)[:, None, None]
+    assert (np.abs(cov[ok] - r_cov[ok]) / scale).max() <= 1e-5
+    assert ok.sum() >= 1000
+    # the drop-in module with the option set gives the same tuple
+    pnp = build_pnp(dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False, initialiser='epnp'))
+    ret, yaw, t, pcov, pmask = pnp(*d)
+    assert torch.equal(ret.cpu(), torch.from_numpy(valid.astype(bool))) and torch.equal(pmask.cpu(), torch.from_numpy(mask.astype(bool)))
+    assert torch.equal(yaw.cpu()[:, 0], torch.from_numpy(pose[:, 0])) and torch.equal(t.cpu(), torch.from_numpy(pose[:, 1:]))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f16'])
+def test_56x56_tiles(dev, orc, dtype):
+    """the config-5 shape (3136 correspondences per object): fp32 storage needs the workspaces to overlay the records (100 KB
+    of records + 49 KB of workspaces do not fit 160 KB of LDS), fp16 storage does not."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+    b = syn.make_batch(B=48, hw=56, seed=4321)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    if dtype == 'f16':
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).transpose(0, 2, 1))).to(dev).to(torch.float16).permute(0, 2, 1)
+        dx2d, distd, dx3d = tt(x2d), tt(istd), tt(x3d)
+        x2d, istd, x3d = [a.float().cpu().numpy() for a in (dx2d, distd, dx3d)]          # the oracle sees the rounded values
+    else:
+        dx2d, distd, dx3d = _t(dev, x2d), _t(dev, istd), _t(dev, x3d)
+    ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_init=True, num_threads=0)
+    ini, imask, ivalid, _, _ = epnp_ransac_device(dx2d, distd, dx3d, _t(dev, K), epnp_istd_thres=0.6, epnp_ransac_thres=_t(dev, thr))
+    valid, pose, cov, tr, mask, diag = [a.cpu().numpy() for a in pnp_uncert_from_init_device(dx2d, distd, dx3d, _t(dev, K), _t(dev, ur), _t(dev, vr), ini, imask,
+                                                                                           ivalid, z_min=0.5, inlier_opt_only=True, with_diag=True)]
+    r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag, r_init = ref
+    assert np.array_equal(mask.astype(bool), r_mask) and np.array_equal(valid.astype(bool), r_ret)
+    assert np.abs(ini.cpu().numpy() - r_init).max() <= INIT_TOL
+    assert np.array_equal(diag[:, 0], r_diag[:, 0]) and np.array_equal(diag[:, 2], r_diag[:, 2])
+    ok = r_ret
+    dyaw = np.abs(np.angle(np.exp(1j * (pose[:, 0] - r_yaw[:, 0]))))
+    assert ok.sum() >= 44 and dyaw[ok].max() <= POSE_TOL and np.abs(pose[:, 1:] - r_t)[ok].max() <= POSE_TOL
+
+
+def test_empty_batch_and_argument_checks(dev):
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    from monorun_amd.ops import pnp_uncert
+    z = lambda *s: torch.zeros(*s, device=dev)
+    ini, imask, ivalid, _, _ = epnp_ransac_device(z(0, 784, 2), z(0, 784, 2), z(0, 784, 3), z(1, 3, 3), epnp_ransac_thres=z(0))
+    assert ini.shape == (0, 4) and imask.shape == (0, 784) and ivalid.shape == (0,)
+    ret, yaw, t, cov, mask = pnp_uncert(z(0, 784, 2), z(0, 784, 2), z(0, 784, 3), z(1, 3, 3), z(1, 2), z(1, 2), epnp_ransac_thres=z(0), initialiser='epnp')
+    assert ret.shape == (0,) and yaw.shape == (0, 1) and t.shape == (0, 3) and cov.shape == (0, 4, 4) and mask.shape == (0, 784)
+    with pytest.raises(ValueError):
+        pnp_uncert(z(1, 784, 2), z(1, 784, 2), z(1, 784, 3), z(1, 3, 3), z(1, 2), z(1, 2), initialiser='cv2')
