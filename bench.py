@@ -555,6 +555,8 @@ def run(args):
             line['speedup_vs_cpu_all_cores'] = line['value'] / cb['cpu_baseline_all_cores']['value']
             if 'cpu_baseline_epnp' in cb:
                 line['speedup_vs_cpu_epnp_1thread'] = line['value'] / cb['cpu_baseline_epnp']['value']
+            if 'cpu_baseline_epnp' in cb and 'value' in extra.get('epnp_initialiser', {}):
+                line['speedup_epnp_initialiser_vs_cpu_epnp_1thread'] = extra['epnp_initialiser']['value'] / cb['cpu_baseline_epnp']['value']
             if 'init_given' in extra:
                 line['speedup_init_given_vs_cpu_1thread'] = extra['init_given']['value'] / cb['cpu_baseline_init_given']['value']
         _emit(line)
@@ -642,6 +644,36 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
             'what': 'host wall per call incl. output allocation and argument marshalling, 1024 objects, after the 4-DoF solve of batch 0'}
     except Exception as e:                                          # noqa: BLE001 — secondary figure
         extra['second_launches'] = {'error': repr(e)}
+    # (g) the reference's own initialiser on the GPU (PnPUncert(initialiser='epnp')): EPnP/RANSAC launch + LM launch, next to cpu_baseline_epnp
+    try:
+        from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+
+        def ep_step():
+            ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
+            return pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, ini, im, iv, z_min=0.5, inlier_opt_only=True)
+        for _ in range(2):
+            out = ep_step()
+        torch.cuda.synchronize()
+        ne = max(4, args.steps // 10)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_init = t_lm = 0.0
+        t1 = time.perf_counter()
+        for _ in range(ne):
+            evs[0].record()
+            ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
+            evs[1].record()
+            out = pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, ini, im, iv, z_min=0.5, inlier_opt_only=True)
+            evs[2].record()
+            torch.cuda.synchronize()
+            t_init += evs[0].elapsed_time(evs[1]); t_lm += evs[1].elapsed_time(evs[2])
+        el = time.perf_counter() - t1
+        extra['epnp_initialiser'] = {'value': B_PER_GPU * ne / el, 'unit': 'solves/s', 'ms_per_step': el / ne * 1e3,
+                                     'epnp_ransac_launch_ms': t_init / ne, 'lm_launch_ms': t_lm / ne, 'valid': int(out[0].sum().item()),
+                                     'what': "pnp_uncert(..., initialiser='epnp') on batch 0: the reference's initialiser (30 EPnP hypotheses on cv::RNG subsets, "
+                                             'consensus, adaptive iteration count, EPnP re-fit) as its own launch, then the LM + covariance launch; masks and '
+                                             'poses equal the CPU restatement (tests/test_gpu_epnp.py); the CPU counterpart is cpu_baseline_epnp'}
+    except Exception as e:                                          # noqa: BLE001 — secondary figure
+        extra['epnp_initialiser'] = {'error': repr(e)}
     # (f) the NOC path at B = 1024: raw head output -> pose, fused (one launch) and as two launches (K2 decode, then the PnP kernel)
     try:
         extra['head_to_pose_1024'] = head_to_pose(torch, syn, PnPLaunch, dev)

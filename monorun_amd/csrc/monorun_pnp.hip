@@ -557,6 +557,7 @@ bool build_plan(PairwisePlan &pl, int P) {
 
 std::atomic<int> g_last_hip_error{0};
 unsigned long long *g_stamps = nullptr;
+unsigned long long *g_ep_time = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
 // What the heuristics below need to know about the device, read once per device from hipGetDeviceProperties (an MI355X reports
@@ -749,6 +750,7 @@ int mr_pnp_last_hip_error(void) { return g_last_hip_error; }
 
 // development aid (not in the public header): device buffer of (B,10) u64 cycle stamps, or NULL to disable
 void mr_pnp_debug_set_stamps(unsigned long long *dev_ptr) { g_stamps = dev_ptr; }
+void mr_epnp_debug_set_times(unsigned long long *dev_ptr) { g_ep_time = dev_ptr; }       // (B,8) phase clocks of the EPnP kernel
 
 // Occupies one wavefront of the device for `microseconds` (100 MHz constant clock).  PnPPipeline uses it to find out which of
 // its streams the runtime really runs side by side: HIP maps streams onto a small number of hardware queues (4 per priority level
@@ -857,6 +859,7 @@ int mr_epnp_ransac_batched(
     }
     ea.init_pose = init_pose; ea.init_mask = init_mask; ea.init_ok = init_valid; ea.diag = diag; ea.dbg_hyp = debug_hypotheses;
     ea.max_iters = max_iters;
+    ea.dbg_time = g_ep_time;
     hipStream_t st = (hipStream_t)stream;
     switch (in_dtype) {
         case MR_F32: return launch_epnp<float>(ea, st);
