@@ -152,6 +152,16 @@ int mr_pnp_uncert_from_init_batched(
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream);
 
 /*
+ * The reference's eigenvalue rule for ill-conditioned Hessians (pnp_uncert.py:77-85), applied per object to the outputs of
+ * mr_pnp_uncert_batched / mr_pnp_uncert_from_init_batched: an object stays valid only if lambda_min(h) > max(1e-6 * lambda_max(h), 0)
+ * (evaluated on cov = h^-1, whose eigenvalues are the reciprocals); otherwise valid[b] = 0 and cov[b] = identity.  The fused kernel
+ * alone invalidates only objects whose h has no Cholesky factorisation; the reference applies this rule — to the whole batch — in
+ * the branch it takes when torch.inverse raises.  valid (B) u8 in/out, cov (B,16) f32 in/out, eig_min_max (B,2) f32 or NULL (the
+ * two extreme eigenvalues of cov, for inspection).
+ */
+int mr_cov_symeig_rule(uint8_t *valid, float *cov, int B, float *eig_min_max, void *stream);
+
+/*
  * True 6-DoF refinement (the flag the reference declares and ignores: `use_6dof`, pnp_uncert.py:11).
  * Second launch of pnp_uncert(..., use_6dof=True): for each object, starting from the 4-DoF result pose4 = [yaw,tx,ty,tz]
  * (r = (0,yaw,0)) on the points of that solve's final inlier_mask, the same residual functor (pnp_uncert_cpu.cpp:24-51) is

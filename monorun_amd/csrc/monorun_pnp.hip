@@ -500,6 +500,57 @@ __global__ void __launch_bounds__(64) spin_kernel(long long ticks) {
     while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// The reference's covariance fallback (pnp_uncert.py:77-85), per object: when torch.inverse raises, the reference keeps an
+// object only if the smallest eigenvalue of its Hessian exceeds max(1e-6 * largest, 0), and sets the others to h := I.  The fused
+// kernel reports "Cholesky failed" instead; this optional pass applies the eigenvalue rule to every object.  The eigenvalues of
+// cov = h^-1 are the reciprocals of h's, so the rule reads lambda_min(cov) > max(1e-6 * lambda_max(cov), 0) on the matrix the
+// kernel already wrote (cyclic Jacobi on the 4x4, fp64).  One thread per object.
+__global__ void __launch_bounds__(64) cov_symeig_rule_kernel(uint8_t *valid, float *cov, int B, float *lam_out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double A[16];
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { A[i] = (double)cov[(long long)b * 16 + i]; finite = finite && isfinite(A[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) { const double m = 0.5 * (A[4 * i + j] + A[4 * j + i]); A[4 * i + j] = A[4 * j + i] = m; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dia += A[5 * i] * A[5 * i];
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) off += A[4 * i + j] * A[4 * i + j];
+        }
+        if (!(off > 1e-30 * dia)) break;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = A[4 * p + q];
+                if (apq != 0.0) {
+                    const double theta = (A[5 * q] - A[5 * p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double x = A[4 * k + p], y = A[4 * k + q]; A[4 * k + p] = c * x - sn * y; A[4 * k + q] = sn * x + c * y; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double x = A[4 * p + k], y = A[4 * q + k]; A[4 * p + k] = c * x - sn * y; A[4 * q + k] = sn * x + c * y; }
+                }
+            }
+    }
+    const double lmin = fmin(fmin(A[0], A[5]), fmin(A[10], A[15])), lmax = fmax(fmax(A[0], A[5]), fmax(A[10], A[15]));
+    if (lam_out) { lam_out[(long long)b * 2] = (float)lmin; lam_out[(long long)b * 2 + 1] = (float)lmax; }
+    const bool keep = finite && (lmin > fmax(1e-6 * lmax, 0.0));
+    if (!keep) {
+        valid[b] = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cov[(long long)b * 16 + i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    }
+}
+
 #include "kitti_eval_kernel.inc"
 
 size_t lds_bytes(const PnpArgs &a, int wpo) {
@@ -867,6 +918,15 @@ int mr_epnp_ransac_batched(
         case MR_F64: return launch_epnp<double>(ea, st);
         default: return MR_ERR_UNSUPPORTED;
     }
+}
+
+int mr_cov_symeig_rule(uint8_t *valid, float *cov, int B, float *eig_min_max, void *stream) {
+    if (B < 0) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!valid || !cov) return MR_ERR_BAD_ARGUMENT;
+    hipLaunchKernelGGL(cov_symeig_rule_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, valid, cov, B, eig_min_max);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
 }
 
 int mr_pnp6_refine_batched(

@@ -130,6 +130,20 @@ def pnp_uncert_from_init_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, 
     return valid, pose, cov, tr, mask, diag
 
 
+def cov_symeig_rule_device(valid_u8, cov, with_eigs=False):
+    """The reference's eigenvalue rule (pnp_uncert.py:77-85) applied IN PLACE to (valid u8 (B,), cov f32 (B,4,4)):
+    objects with lambda_min(h) <= max(1e-6 lambda_max(h), 0) become invalid and get cov = I (``mr_cov_symeig_rule``)."""
+    lib = _lib.load()
+    B = int(valid_u8.shape[0])
+    assert valid_u8.dtype == torch.uint8 and cov.dtype == torch.float32 and cov.is_contiguous() and valid_u8.is_contiguous()
+    lam = torch.empty(B, 2, device=cov.device, dtype=torch.float32) if with_eigs else None
+    if B > 0:
+        with torch.cuda.device(cov.device):
+            _lib.check(lib.mr_cov_symeig_rule(valid_u8.data_ptr(), cov.data_ptr(), B, lam.data_ptr() if lam is not None else None,
+                                              torch.cuda.current_stream(cov.device).cuda_stream))
+    return lam
+
+
 class PnPLaunch:
     """A prepared launch of the fused kernel over device-resident inputs with preallocated outputs:
     every ctypes argument is built once, ``run()`` only enqueues the kernel on the current stream.
@@ -352,7 +366,7 @@ def exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range
 
 
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
-               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser='k0'):
+               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser='k0', cov_symeig_rule=False):
     """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
 
     coords_2d / coords_2d_istd (B,P,2), coords_3d (B,P,3), cam_mats (B|1,3,3), u_range / v_range (B|1,2),
@@ -365,6 +379,10 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     launch); 'epnp' = the reference's own initialiser — cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP),
     pnp_uncert_cpu.py:33-68 — as its own launch in front of the LM (two launches; the published algorithm as DESIGN.md §5 restates
     it: inlier sets, start pose and hence the returned pose are then the reference flow's, up to what OpenCV's own build would do).
+    cov_symeig_rule (not a reference keyword): also apply, per object, the eigenvalue test of the reference's fallback branch
+    (pnp_uncert.py:77-85: keep an object only if lambda_min(h) > max(1e-6 lambda_max(h), 0), else ret_val = False and pose_cov = I).
+    Default False = this kernel's own rule (an object is dropped when h has no Cholesky factorisation), which is what the
+    reference does whenever torch.inverse does not raise.
     use_6dof=False (every shipped config): returns (ret_val (B,) bool, r_vec (B,1) yaw, t_vec (B,3), pose_cov (B,4,4) covariance of
     [yaw, t], inlier_mask (B,P) bool) on the device and in the dtype of coords_2d — the reference's tuple.
     use_6dof=True: the flag the reference declares and never reads (pnp_uncert.py:11) made real — after the 4-DoF solve (mask,
@@ -399,6 +417,9 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
                     pose6[:, 3:].to(device=src_dev, dtype=odt), cov6.to(device=src_dev, dtype=odt), mask.to(device=src_dev, dtype=torch.bool))
         if forward_exact_hessian:
             valid, cov, _ = exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, pose, mask, valid, z_min=z_min)
+        if cov_symeig_rule:
+            cov = cov.contiguous()
+            cov_symeig_rule_device(valid, cov)
         ret_val = valid.to(device=src_dev, dtype=torch.bool)
         r_vec = pose[:, :1].to(device=src_dev, dtype=odt)
         t_vec = pose[:, 1:].to(device=src_dev, dtype=odt)

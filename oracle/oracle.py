@@ -164,6 +164,21 @@ def pose_cov(H):
     return bool(ok), cov
 
 
+def cov_symeig_rule(valid, cov):
+    """The reference's eigenvalue rule (pnp_uncert.py:77-85) per object, restated on cov = h^-1 (reciprocal eigenvalues):
+    keep iff lambda_min(cov) > max(1e-6 lambda_max(cov), 0); otherwise valid = False, cov = I.  Returns (valid, cov, eigs (B,2))."""
+    valid, cov = np.array(valid, bool), np.array(cov, np.float32)
+    lam = np.zeros((len(valid), 2))
+    for i in range(len(valid)):
+        c = cov[i].astype(np.float64)
+        w = np.linalg.eigvalsh(0.5 * (c + c.T)) if np.isfinite(c).all() else np.array([np.nan] * 4)
+        lam[i] = (w[0], w[-1])
+        if not (np.isfinite(c).all() and w[0] > max(1e-6 * w[-1], 0.0)):
+            valid[i] = False
+            cov[i] = np.eye(4, dtype=np.float32)
+    return valid, cov, lam
+
+
 def k0_init(x2d, x3d, mask0, K, ransac_thr=None, n_hyp=32):
     """K0 for one object.  Returns dict(ok, init_pose, mask, best_hyp, best_count)."""
     x2d, x3d, K = _f(x2d), _f(x3d), _f(K)

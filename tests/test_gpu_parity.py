@@ -509,3 +509,54 @@ def test_legacy_entry_point_from_many_threads(dev, orc, batch64):
     for b in batched[1:]:
         assert torch.equal(b[1], batched[0][1]) and torch.equal(b[4], batched[0][4])
     assert int(batched[0][0].sum()) >= 60
+
+
+def test_reference_eigenvalue_rule_for_ill_conditioned_hessians(dev, orc):
+    """pnp_uncert.py:77-85: in the branch the reference takes when torch.inverse raises, an object stays valid only if
+    lambda_min(h) > max(1e-6 lambda_max(h), 0), the others get h := I.  The fused kernel alone drops an object only when h has no
+    Cholesky factorisation; `mr_cov_symeig_rule` / pnp_uncert(..., cov_symeig_rule=True) applies the eigenvalue test per object.
+    (a) the pass against numpy on synthetic covariances spanning condition numbers 1 ... 1e12, indefinite, NaN;
+    (b) objects whose yaw is unobservable (all correspondences on the rotation axis ... nearly): valid without the rule, dropped with it."""
+    from monorun_amd.ops.least_squares.pnp_uncert import cov_symeig_rule_device
+    from monorun_amd.ops import pnp_uncert
+    rng = np.random.default_rng(12)
+    covs = []
+    for cond in (1.0, 1e2, 1e5, 9e5, 1.1e6, 1e7, 1e12):
+        for _ in range(8):
+            q, _ = np.linalg.qr(rng.normal(size=(4, 4)))
+            lam = np.array([1.0, cond ** (1 / 3), cond ** (2 / 3), cond]) * rng.uniform(1e-4, 1e2)
+            covs.append(q @ np.diag(lam) @ q.T)
+    q, _ = np.linalg.qr(rng.normal(size=(4, 4)))
+    covs.append(q @ np.diag([-1e-3, 1.0, 2.0, 3.0]) @ q.T)                   # indefinite
+    covs.append(np.full((4, 4), np.nan)); covs.append(np.eye(4))
+    cov = np.stack(covs).astype(np.float32)
+    valid = np.ones(len(cov), np.uint8)
+    dv, dc = torch.from_numpy(valid).to(dev), torch.from_numpy(cov).to(dev)
+    lam = cov_symeig_rule_device(dv, dc, with_eigs=True)
+    torch.cuda.synchronize()
+    r_valid, r_cov, r_lam = orc.cov_symeig_rule(valid, cov)
+    # the eigenvalue test itself is compared away from its own threshold (float32 covariances: the ratio is known to ~1e-6 relative)
+    ratio = r_lam[:, 0] / np.where(r_lam[:, 1] != 0, r_lam[:, 1], 1.0)
+    clear = ~np.isfinite(ratio) | (np.abs(ratio / 1e-6 - 1.0) > 0.05)
+    assert np.array_equal(dv.cpu().numpy().astype(bool)[clear], r_valid[clear])
+    same = dv.cpu().numpy().astype(bool) == r_valid
+    assert np.array_equal(dc.cpu().numpy()[same], r_cov[same])
+    fin = np.isfinite(r_lam).all(1)
+    assert np.allclose(lam.cpu().numpy()[fin], r_lam[fin], rtol=1e-4, atol=1e-7 * np.abs(r_lam[fin]).max(1, keepdims=True))
+    assert r_valid[:32].all() and not r_valid[40:56].any()                      # cond <= 9e5 kept, >= 1e7 dropped
+    # (b) end to end: a far object seen through correspondences that all lie within 2 mm of the rotation axis: the yaw column of J is ~0
+    b = syn.make_batch(B=24, seed=5)
+    x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+    x3d = x3d.copy()
+    x3d[:6, :, 0] *= 1e-3; x3d[:6, :, 2] *= 1e-3
+    t = lambda a: torch.from_numpy(a).to(dev)
+    init = np.concatenate([b['gt_yaw'][:, None], b['gt_t']], 1)
+    outs = {}
+    for rule in (False, True):
+        outs[rule] = [o.cpu().numpy() for o in pnp_uncert(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), 0.5, 0.6, None, False, cov_symeig_rule=rule)]
+    h_valid, h_cov, h_lam = orc.cov_symeig_rule(outs[False][0], outs[False][3])
+    clear = np.abs((h_lam[:, 0] / h_lam[:, 1]) / 1e-6 - 1.0) > 0.05
+    assert np.array_equal(outs[True][0][clear], h_valid[clear])
+    assert outs[False][0][:6].all() and not outs[True][0][:6].any(), 'the six degenerate objects are valid without the rule and dropped by it'
+    assert np.array_equal(outs[True][3][~outs[True][0]], np.broadcast_to(np.eye(4, dtype=np.float32), (int((~outs[True][0]).sum()), 4, 4)))
+    assert outs[True][0][6:].sum() >= 16

@@ -43,4 +43,19 @@ out['3it_obj_alone'] = ev_time(mk(batches[0], torch.tensor([i3], device=dev)))
 out['first100'] = ev_time(mk(batches[0], torch.arange(100, device=dev)))
 keep = torch.tensor(np.where(it <= 5)[0], device=dev)
 out['b0_le5it(%d)' % len(keep)] = ev_time(mk(batches[0], keep))
+# the headline regime: 12 rotating batches, 4 launches in flight, the pipeline's wave count
+if os.environ.get('KPERF_PIPE', '1') == '1':
+    from monorun_amd import PnPPipeline
+    nb = [batches[0]] + [[dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=1234 + 7919 * i), planar=True)] for i in range(1, 11)] + [batches[1]]
+    pipe = PnPPipeline(dev, depth=4)
+    fl = pipe.flags_for(1024, 784)
+    ls = [[PnPLaunch(*b[:6], 0.5, 0.6, b[6], True, flags=fl) for b in nb] for _ in range(8)]
+    res = []
+    for rep in range(5):
+        for i in range(12): pipe.submit(ls[i % 8][i % 12], slot=i % 8)
+        pipe.drain(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(240): pipe.submit(ls[i % 8][i % 12], slot=i % 8)
+        pipe.drain()
+        res.append((time.perf_counter() - t0) / 240 * 1e6)
+    out['pipe4_us_per_step'] = (float(np.median(res)), float(min(res)))
 print(f'[{tag}] ' + '  '.join(f'{k}={v[0]:.1f}/{v[1]:.1f}' for k, v in out.items()) + '  (median/min us)')
