@@ -139,5 +139,63 @@ def main():
           ' iterations max', int(out['iters'].max()), ' candidate pool', n_pool, ' QR/Cholesky divergent (excluded)', diverge, ' tags', dict(zip(*[a.tolist() for a in np.unique(out['tag'], return_counts=True)])))
 
 
+def main_b():
+    """Golden fixture G7b — the candidates G7 leaves OUT: starts where the Jacobi-scaled J is numerically rank-deficient (initial
+    pose at / behind the camera: every point z-clamped, a column without information; or > 10 m off), so that the LM's two step
+    solvers part ways — Ceres' DENSE_QR on [J S; D] versus the Cholesky factorisation of the normal equations that the HIP kernel
+    uses.  For these inputs the kernel can only be pinned to its OWN step solver: the fixture freezes the oracle's CHOLESKY-mode
+    trajectories (same columns as G7) and records, per object, what the QR mode returns (iterations, exit reason, pose), so that the
+    gap is a committed number (profiles/r03_g7b_qr_vs_cholesky.txt is printed from it)."""
+    picked = []
+    n_pool = 0
+    for tag, o in candidates():
+        rq = solve(o, qr=True)
+        rc = solve(o, qr=False, trace=True)
+        n_pool += 1
+        if rc['iters'] != rq['iters'] or rc['why'] != rq['why'] or (rq['val'] and np.abs(rc['pose'] - rq['pose']).max() > 1e-7 * max(1.0, np.abs(rq['pose']).max())):
+            picked.append((tag, o, rc, rq))
+    n = len(picked)
+    out = dict(x2d=np.stack([p[1]['x2d'] for p in picked]), w=np.stack([p[1]['w'] for p in picked]), x3d=np.stack([p[1]['x3d'] for p in picked]),
+               K=np.stack([p[1]['K'] for p in picked]), ur=np.stack([p[1]['ur'] for p in picked]), vr=np.stack([p[1]['vr'] for p in picked]),
+               init=np.stack([p[1]['init'] for p in picked]), tag=np.array([p[0] for p in picked]))
+    trace = np.full((n, MAXP, len(orc.TRACE_FIELDS)), np.nan)
+    for i, (tag, o, rc, rq) in enumerate(picked):
+        assert len(rc['trace']) <= MAXP
+        trace[i, :len(rc['trace'])] = rc['trace']
+    out.update(trace=trace, n_pass=np.array([len(p[2]['trace']) for p in picked], np.int32), iters=np.array([p[2]['iters'] for p in picked], np.int32),
+               why=np.array([p[2]['why'] for p in picked], np.int32), val=np.array([p[2]['val'] for p in picked], np.int32),
+               pose=np.stack([p[2]['pose'] for p in picked]), radius=np.array([p[2]['tr'] for p in picked]),
+               final_cost=np.array([p[2]['final_cost'] for p in picked]), trace_fields=np.array(orc.TRACE_FIELDS),
+               qr_iters=np.array([p[3]['iters'] for p in picked], np.int32), qr_why=np.array([p[3]['why'] for p in picked], np.int32),
+               qr_val=np.array([p[3]['val'] for p in picked], np.int32), qr_pose=np.stack([p[3]['pose'] for p in picked]),
+               qr_final_cost=np.array([p[3]['final_cost'] for p in picked]), pool_size=np.int32(n_pool))
+    path = os.path.join(ROOT, 'tests', 'golden', 'g7b_lm_rank_deficient_starts.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes;', n, 'objects of a pool of', n_pool)
+    report(out)
+
+
+def report(z):
+    """per-object gap between the two step solvers on the G7b objects (the text committed as profiles/r03_g7b_qr_vs_cholesky.txt)"""
+    print('# G7b: LM starts where Cholesky (normal equations; the HIP kernel) and DENSE_QR (Ceres) part ways — oracle, fp64')
+    print('# obj tag        iters(chol/qr) exit(chol/qr) valid(chol/qr)  max|pose_chol - pose_qr|   cost_chol        cost_qr')
+    gaps = []
+    for i in range(len(z['iters'])):
+        gap = float(np.abs(z['pose'][i] - z['qr_pose'][i]).max())
+        gaps.append(gap)
+        print(f"{i:4d} {str(z['tag'][i]):10s} {int(z['iters'][i]):3d}/{int(z['qr_iters'][i]):<3d}        {int(z['why'][i])}/{int(z['qr_why'][i])}           {int(z['val'][i])}/{int(z['qr_val'][i])}        "
+              f"{gap:12.4e}          {float(z['final_cost'][i]):12.6e} {float(z['qr_final_cost'][i]):12.6e}")
+    gaps = np.array(gaps)
+    same_exit = (z['why'] == z['qr_why']) & (z['iters'] == z['qr_iters'])
+    lower = z['final_cost'] <= z['qr_final_cost'] * (1 + 1e-9)
+    print(f'# {len(gaps)} objects; identical iteration count and exit reason: {int(same_exit.sum())}; pose gap median {np.median(gaps):.3e}, p90 {np.percentile(gaps, 90):.3e}, '
+          f'max {gaps.max():.3e}; objects within 1e-4: {int((gaps <= 1e-4).sum())}; final cost of the Cholesky mode <= the QR mode\'s in {int(lower.sum())} objects')
+
+
 if __name__ == '__main__':
-    main()
+    if '--b' in sys.argv:
+        main_b()
+    elif '--report-b' in sys.argv:
+        report(dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'g7b_lm_rank_deficient_starts.npz'), allow_pickle=True)))
+    else:
+        main()
