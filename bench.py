@@ -476,11 +476,12 @@ def run(args):
             except Exception:  # noqa: BLE001
                 traffic = None
         valu = None
-        for sname in ('r02_summary.json', 'r01_summary.json'):           # PMC instruction counts of the same command
+        for sname in ('r03_summary.json', 'r02_summary.json', 'r01_summary.json'):           # PMC instruction counts of the same command
             sfile = os.path.join(ROOT, 'profiles', sname)
             if os.path.exists(sfile) and not stress:
                 try:
-                    cnt = json.load(open(sfile))['counters']['SQ_INSTS_VALU']['mean']
+                    sj = json.load(open(sfile))
+                    cnt = (sj['single_stream'] if 'single_stream' in sj else sj)['counters']['SQ_INSTS_VALU']['mean']      # the isolated (4-wave) kernel
                     # every VALU wave-instruction occupies its SIMD for >= 2 (fp32) .. 4 (fp64) cycles; 1024 SIMDs at 2.4 GHz
                     t_min = cnt * 4.0 / (1024 * 2.4e9)
                     valu = {'valu_insts_per_launch': cnt, 'min_issue_time_us_at_4_cycles': t_min * 1e6,

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_round.sh output directory (gpurun_out/prof_<tag>) into the tracked
-profiles/<tag>_* files: kernel stats CSV (verbatim), per-kernel PMC means, the bench line, host info,
-and profiles/traffic.json (HBM bytes per launch, corrected as MI355X_MICROARCH.md §HBM prescribes)."""
+"""Condense a tools/profile_round.sh output directory (gpurun_out/prof_<tag>) into the tracked profiles/<tag>_* files:
+kernel-stats CSVs (verbatim) of both bench regimes, of the NOC path and of the EPnP initialiser, per-kernel PMC means, the
+bench lines, host info, and profiles/traffic.json (HBM bytes per launch, corrected as MI355X_MICROARCH.md §HBM prescribes)."""
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
@@ -11,58 +12,113 @@ import sys
 
 import numpy as np
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', f'prof_{tag}')
 dst = os.path.join(root, 'profiles')
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, 'trace', 't_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+
+
+def find(sub, name):
+    hits = glob.glob(os.path.join(src, sub, '**', name), recursive=True)
+    return hits[0] if hits else None
+
+
+def stats_rows(sub):
+    f = find(sub, 't_kernel_stats.csv')
+    return list(csv.DictReader(open(f))) if f else []
+
+
+def counters(sub, needle):
+    """per-launch means of every counter of the kernels whose name contains `needle` in one --pmc pass"""
+    f = find(sub, 'p_counter_collection.csv')
+    if not f:
+        return {}, None
+    acc, meta = collections.defaultdict(list), None
+    for r in csv.DictReader(open(f)):
+        if needle in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+            meta = dict(kernel=r['Kernel_Name'], grid=int(r['Grid_Size']), workgroup=int(r['Workgroup_Size']), vgpr=int(r['VGPR_Count']),
+                        sgpr=int(r['SGPR_Count']), scratch=int(r['Scratch_Size']), lds=int(r.get('LDS_Block_Size', 0) or 0))
+    return {k: dict(mean=float(np.mean(v)), min=float(np.min(v)), max=float(np.max(v)), launches=len(v)) for k, v in acc.items()}, meta
+
+
+def kernel_block(prefix, needle, passes=('fetch', 'write', 'sq', 'lds'), trace=None, alg_bytes=None):
+    cnt, meta = {}, None
+    for p in passes:
+        c, m = counters(f'{prefix}_{p}' if not prefix.startswith('pmc') else f'{prefix}_{p}', needle)
+        cnt.update(c)
+        meta = meta or m
+    rows = [r for r in stats_rows(trace) if needle in r['Name']]
+    out = dict(kernel=meta, counters=cnt)
+    if rows:
+        out['rocprof_kernel_avg_us'] = float(rows[0]['AverageNs']) / 1e3
+        out['rocprof_calls'] = int(rows[0]['Calls'])
+        out['rocprof_min_us'], out['rocprof_max_us'] = float(rows[0]['MinNs']) / 1e3, float(rows[0]['MaxNs']) / 1e3
+    if 'FETCH_SIZE' in cnt and 'WRITE_SIZE' in cnt:
+        hbm = (2 * cnt['FETCH_SIZE']['mean'] + cnt['WRITE_SIZE']['mean']) * 1024
+        out['traffic'] = dict(hbm_bytes_per_launch=hbm, fetch_size_kb_raw=cnt['FETCH_SIZE']['mean'], write_size_kb_raw=cnt['WRITE_SIZE']['mean'],
+                              fetch_correction='x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md §HBM; calibrated for 4 B/lane and 16 B/lane '
+                                               'reads in profiles/r02_fetch_calibration.txt)')
+        if alg_bytes:
+            out['traffic'].update(algorithmic_bytes_per_launch=alg_bytes, ratio_traffic_over_algorithmic=hbm / alg_bytes)
+            if rows:
+                out['hbm_roofline'] = dict(achieved_GBps=alg_bytes / (out['rocprof_kernel_avg_us'] * 1e-6) / 1e9, peak_GBps=8000.0,
+                                           frac=alg_bytes / (out['rocprof_kernel_avg_us'] * 1e-6) / 1e9 / 8000.0)
+    if 'SQ_WAVES' in cnt and cnt['SQ_WAVES']['mean'] > 0:
+        w = cnt['SQ_WAVES']['mean']
+        d = dict(waves_per_launch=w)
+        for k, name in (('SQ_INSTS_VALU', 'valu_insts_per_wave'), ('SQ_INSTS_SALU', 'salu_insts_per_wave'), ('SQ_INSTS_LDS', 'lds_insts_per_wave'), ('SQ_INSTS_VMEM', 'vmem_insts_per_wave')):
+            if k in cnt:
+                d[name] = cnt[k]['mean'] / w
+        if 'SQ_WAVE_CYCLES' in cnt:
+            wc = cnt['SQ_WAVE_CYCLES']['mean']
+            for k, name in (('SQ_ACTIVE_INST_ANY', 'active_frac_of_wave_cycles'), ('SQ_WAIT_ANY', 'wait_any_frac'), ('SQ_WAIT_INST_ANY', 'wait_inst_frac')):
+                if k in cnt:
+                    d[name] = cnt[k]['mean'] / wc
+            if rows:       # SQ_WAVE_CYCLES counts quad-cycles of resident waves; 1024 SIMDs at the 2.4 GHz peak clock (a lower bound of the residency if the clock was lower)
+                d['mean_resident_waves_per_simd'] = 4.0 * wc / (out['rocprof_kernel_avg_us'] * 2400.0 * 1024)
+        if 'SQ_LDS_BANK_CONFLICT' in cnt and cnt.get('SQ_LDS_IDX_ACTIVE', {}).get('mean', 0) > 0:
+            d['lds_bank_conflict_frac'] = cnt['SQ_LDS_BANK_CONFLICT']['mean'] / cnt['SQ_LDS_IDX_ACTIVE']['mean']
+        if 'SQ_INSTS_VALU' in cnt and rows:
+            d['valu_min_issue_us_at_4_cycles'] = cnt['SQ_INSTS_VALU']['mean'] * 4.0 / (1024 * 2.4e9) * 1e6
+            d['valu_issue_frac_of_kernel_time'] = d['valu_min_issue_us_at_4_cycles'] / out['rocprof_kernel_avg_us']
+        out['derived'] = d
+    return out
+
+
+for sub, name in (('trace1', 'kernel_stats'), ('trace4', 'kernel_stats_in_flight'), ('noc_k2_trace', 'k2_kernel_stats'), ('noc_fused_trace', 'fused_kernel_stats'),
+                  ('epnp_trace', 'epnp_kernel_stats')):
+    f = find(sub, 't_kernel_stats.csv')
+    if f:
+        shutil.copy(f, os.path.join(dst, f'{tag}_{name}.csv'))
 for f in ('lscpu.txt', 'rocminfo.txt'):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f'{tag}_{f}'))
 bench = open(os.path.join(src, 'bench.json')).read().strip().split('\n')[-1]
 open(os.path.join(dst, f'{tag}_bench.json'), 'w').write(bench + '\n')
-counters, meta = {}, None
-for d in sorted(os.listdir(src)):
-    f = os.path.join(src, d, 'p_counter_collection.csv')
-    if not os.path.exists(f):
-        continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if 'pnp_uncert_kernel' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-            meta = dict(kernel=r['Kernel_Name'], grid=int(r['Grid_Size']), workgroup=int(r['Workgroup_Size']),
-                        vgpr=int(r['VGPR_Count']), sgpr=int(r['SGPR_Count']), scratch=int(r['Scratch_Size']))
-    for k, v in acc.items():
-        counters[k] = dict(mean=float(np.mean(v)), min=float(np.min(v)), max=float(np.max(v)), launches=len(v), pass_dir=d)
+if os.path.exists(os.path.join(src, 'bench_240.json')):
+    open(os.path.join(dst, f'{tag}_bench_240_steps.json'), 'w').write(open(os.path.join(src, 'bench_240.json')).read().strip().split('\n')[-1] + '\n')
 b = json.loads(bench)
-fetch_kb = counters['FETCH_SIZE']['mean']; write_kb = counters['WRITE_SIZE']['mean']
-# gfx950: FETCH_SIZE tallies 128-B requests at 64 B for coalesced streaming reads -> double it.  The guide states this for
-# 16 B/lane reads; the kernel's HBM reads are one dword per lane (load_records), so the factor was calibrated for that width too:
-# profiles/r02_fetch_calibration.txt (tools/ubench/fetch_calib.hip: counter / true bytes = 0.5000 at 4 B/lane and at 16 B/lane).
-# WRITE_SIZE is used as reported.
-hbm = (2 * fetch_kb + write_kb) * 1024
-traffic = dict(tag=tag, hbm_bytes_per_launch=hbm, fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb,
-               fetch_correction='x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B; MI355X_MICROARCH.md §HBM; calibrated for 4 B/lane reads in profiles/r02_fetch_calibration.txt)',
-               source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary` (tools/profile_round.sh {tag})',
-               algorithmic_bytes_per_launch=b['roofline']['algorithmic_bytes_per_launch'],
-               ratio_traffic_over_algorithmic=hbm / b['roofline']['algorithmic_bytes_per_launch'])
-json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-stats = [r for r in csv.DictReader(open(os.path.join(src, 'trace', 't_kernel_stats.csv'))) if 'pnp_uncert_kernel' in r['Name']][0]
-summ = dict(tag=tag, kernel=meta, rocprof_kernel_avg_us=float(stats['AverageNs']) / 1e3, rocprof_calls=int(stats['Calls']),
-            bench_kernel_avg_us=b['roofline']['kernel_ms_avg'] * 1e3, counters=counters, traffic=traffic,
-            derived=dict(valu_insts_per_wave=counters['SQ_INSTS_VALU']['mean'] / counters['SQ_WAVES']['mean'],
-                         salu_insts_per_wave=counters['SQ_INSTS_SALU']['mean'] / counters['SQ_WAVES']['mean'],
-                         lds_insts_per_wave=counters['SQ_INSTS_LDS']['mean'] / counters['SQ_WAVES']['mean'],
-                         vmem_insts_per_wave=counters['SQ_INSTS_VMEM']['mean'] / counters['SQ_WAVES']['mean'],
-                         active_frac_of_wave_cycles=counters['SQ_ACTIVE_INST_ANY']['mean'] / counters['SQ_WAVE_CYCLES']['mean'],
-                         wait_any_frac=counters['SQ_WAIT_ANY']['mean'] / counters['SQ_WAVE_CYCLES']['mean'],
-                         wait_inst_frac=counters['SQ_WAIT_INST_ANY']['mean'] / counters['SQ_WAVE_CYCLES']['mean'],
-                         lds_bank_conflict_frac=counters['SQ_LDS_BANK_CONFLICT']['mean'] / counters['SQ_LDS_IDX_ACTIVE']['mean'],
-                         waves_per_launch=counters['SQ_WAVES']['mean'],
-                         # SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md); divided by the launch's
-                         # cycles on 1024 SIMDs (at the 2.4 GHz peak clock: a LOWER bound of the occupancy if the clock was lower)
-                         mean_resident_waves_per_simd=4.0 * counters['SQ_WAVE_CYCLES']['mean'] / (float(stats['AverageNs']) / 1e3 * 2400.0 * 1024)))
+alg = b['roofline']['algorithmic_bytes_per_launch']
+P, B = 784, 1024
+summ = dict(tag=tag,
+            single_stream=kernel_block('pmc1', 'pnp_uncert_kernel<float, 4', trace='trace1', alg_bytes=alg),
+            in_flight=kernel_block('pmc4', 'pnp_uncert_kernel<float, 2', trace='trace4', alg_bytes=alg),
+            k2_noc_decode=kernel_block('noc_k2', 'noc_decode_kernel', passes=('fetch', 'write', 'sq'), trace='noc_k2_trace', alg_bytes=B * P * 48 + B * 80),
+            fused_head_to_pose=kernel_block('noc_fused', 'pnp_uncert_kernel', passes=('fetch', 'write', 'sq'), trace='noc_fused_trace',
+                                            alg_bytes=B * (P * 20 + 52 + 85 + P + 64 + 24)),
+            epnp_ransac=kernel_block('epnp', 'epnp_ransac_kernel', passes=('sq', 'lds'), trace='epnp_trace'),
+            bench_kernel_avg_us=b['roofline']['kernel_ms_avg'] * 1e3, bench_value=b['value'], bench_single_stream=b.get('single_stream', {}).get('value'))
 json.dump(summ, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
-print(json.dumps(summ['derived'], indent=1)); print(json.dumps(traffic, indent=1))
-print('rocprof avg us', summ['rocprof_kernel_avg_us'], 'bench events avg us', summ['bench_kernel_avg_us'])
+t1 = summ['single_stream'].get('traffic')
+if t1:
+    traffic = dict(tag=tag, **t1, source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 96 --warmup 12 --no-cpu-baseline --no-secondary --in-flight 1` '
+                                          f'(tools/profile_round.sh {tag}): the 4-waves-per-object kernel of isolated launches, what roofline.achieved is computed from',
+                   in_flight_kernel=summ['in_flight'].get('traffic'))
+    json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+for k in ('single_stream', 'in_flight', 'k2_noc_decode', 'fused_head_to_pose', 'epnp_ransac'):
+    blk = summ[k]
+    print(k, 'avg us', blk.get('rocprof_kernel_avg_us'), 'calls', blk.get('rocprof_calls'), 'traffic ratio', (blk.get('traffic') or {}).get('ratio_traffic_over_algorithmic'),
+          'roofline', (blk.get('hbm_roofline') or {}).get('frac'), 'derived', json.dumps(blk.get('derived')))
+print('bench events avg us', summ['bench_kernel_avg_us'], 'value', b['value'], 'single_stream', summ['bench_single_stream'])
