@@ -35,7 +35,7 @@ def _kitti_val():
     return m
 
 
-def run_split(paths, init_mode, threads, img_shape=(375, 1242)):
+def run_split(paths, init_mode, threads, img_shape=(375, 1242), gpu=None):
     ids = [l.strip() for l in open(paths['ids']) if l.strip()]
     infos, results, stats = [], [], dict(valid=0, n=0)
     for iid in ids:
@@ -48,8 +48,20 @@ def run_split(paths, init_mode, threads, img_shape=(375, 1242)):
         c3d, c3v = orc.noc_decode(noc, dims, dims_var)
         ls_px = orc.decode_logstd(ls, c3v, exp=orc.spec_expf, log=orc.spec_logf)
         x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(orc.roi_grid(d['rois']), ls_px, c3d, img_shape, exp=orc.spec_expf)
-        ret, yaw, t, cov, _, mask = orc.u2d_pnp(x2d, istd, x3d, infos[-1]['cam_intrinsic'][None], ur, vr, 0.5, 0.6, thr, True,
-                                                init_mode=init_mode, num_threads=threads)
+        if gpu is None:
+            ret, yaw, t, cov, _, mask = orc.u2d_pnp(x2d, istd, x3d, infos[-1]['cam_intrinsic'][None], ur, vr, 0.5, 0.6, thr, True,
+                                                    init_mode=init_mode, num_threads=threads)
+        else:                                    # the HIP path in the loop: monorun_amd.ops.pnp_uncert on the same PnP-boundary tensors
+            import torch
+            from monorun_amd.ops import pnp_uncert
+            def tt(a_):                          # same strides on the device as on the host: the layout decides numpy's summation order of the istd mean
+                h = torch.from_numpy(np.asarray(a_))
+                d_ = torch.empty_strided(h.shape, h.stride(), dtype=h.dtype, device=gpu)
+                d_.copy_(h)
+                return d_
+            o = pnp_uncert(tt(x2d), tt(istd), tt(x3d), tt(infos[-1]['cam_intrinsic'][None].astype(np.float32)), tt(ur), tt(vr), 0.5, 0.6, tt(thr), True,
+                           initialiser='epnp' if init_mode == 1 else 'k0')
+            ret, yaw, t, cov, mask = [v.cpu().numpy() for v in o]
         stats['valid'] += int(ret.sum()); stats['n'] += n
         scores = d['scores'] * ret
         import torch
@@ -69,6 +81,7 @@ def main():
     ap.add_argument('--threads', type=int, default=min(16, orc.max_threads()))
     ap.add_argument('--outliers', type=float, default=0.1, help='share of gross outliers among the correspondences')
     ap.add_argument('--noise', type=float, default=0.03, help='3-D noise of the inlier correspondences (m)')
+    ap.add_argument('--gpu', action='store_true', help='also run both initialisers through the HIP path (pnp_uncert(initialiser=...)) and compare')
     a = ap.parse_args()
     kv = _kitti_val()
     tmp = tempfile.mkdtemp(prefix='mr_ap_')
@@ -78,6 +91,19 @@ def main():
     for name, mode in (('K0', 0), ('EPnP', 1)):
         out[name] = run_split(paths, mode, a.threads)
         print(f'{name}: valid {out[name][1]["valid"]} / {out[name][1]["n"]}')
+    if a.gpu:
+        import torch
+        dev = torch.device('cuda:0')
+        for name, mode in (('K0', 0), ('EPnP', 1)):
+            g = run_split(paths, mode, a.threads, gpu=dev)
+            c = out[name]
+            nm = sum(int((r0['_pose'][3] != r1['_pose'][3]).any(1).sum()) for r0, r1 in zip(g[2], c[2]))
+            nv = sum(int((r0['_pose'][0] != r1['_pose'][0]).sum()) for r0, r1 in zip(g[2], c[2]))
+            dp = max(float(np.abs(np.concatenate([np.angle(np.exp(1j * (r0['_pose'][1] - r1['_pose'][1]))), r0['_pose'][2] - r1['_pose'][2]], 1))[r1['_pose'][0]].max(initial=0.0))
+                     for r0, r1 in zip(g[2], c[2]))
+            dap = max(float(np.abs(np.asarray(g[0][crit][key], float) - np.asarray(c[0][crit][key], float)).max()) for crit in ('R40', 'R11') for key in c[0][crit] if key in g[0][crit])
+            print(f'{name} on the GPU vs its CPU restatement: valid {g[1]["valid"]} / {g[1]["n"]}; objects with a different inlier mask {nm}, with a different valid flag {nv}; '
+                  f'largest pose difference {dp:.2e}; largest |dAP| over all classes / metrics / difficulties / criteria {dap:.4f}')
     same = agree = 0
     for r0, r1 in zip(out['K0'][2], out['EPnP'][2]):
         m0, m1 = r0['_pose'][3], r1['_pose'][3]
