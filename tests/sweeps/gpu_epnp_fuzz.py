@@ -1,0 +1,53 @@
+"""Adversarial inputs for the EPnP / RANSAC initialiser path (pnp_uncert(..., initialiser='epnp')): the kernels must terminate, never
+report a non-finite pose as valid, and agree with the reference's flow restated on the success flags and inlier masks (development
+aid; run under `timeout`)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from monorun_amd import synthetic as syn
+from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+from oracle import oracle as orc
+dev = torch.device('cuda:0')
+rng = np.random.default_rng(int(os.environ.get('SEED', 0)))
+def dv(a):
+    t = torch.from_numpy(np.asarray(a)); d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev); d.copy_(t); return d
+bad = 0
+nobj = 0
+for trial in range(int(os.environ.get('TRIALS', 40))):
+    B = int(rng.choice([1, 3, 64, 200])); hw = int(rng.choice([3, 4, 8, 10, 28]))
+    b = syn.make_batch(B=B, hw=hw, seed=int(rng.integers(1 << 30)))
+    x2d, istd, x3d, K, ur, vr, thr = [np.array(a, copy=True) for a in syn.pnp_boundary(b, planar=bool(rng.integers(2)))]
+    P = x2d.shape[1]
+    mode = trial % 10
+    sel = rng.uniform(size=B) < 0.5
+    if mode == 0: x3d[sel] = 0.0                                   # all points coincide
+    elif mode == 1: x2d[sel, rng.integers(P)] = np.nan             # NaN correspondences
+    elif mode == 2: istd[sel] = 0.0                                # zero weights
+    elif mode == 3: x3d[sel] *= 1e20                               # overflow
+    elif mode == 4: x3d[sel, :, 1] = 0.0                           # planar object (rank-2 covariance: one control point collapses)
+    elif mode == 5: x3d[sel] = rng.normal(0, 1, x3d[sel].shape).astype(np.float32)   # garbage geometry
+    elif mode == 6: thr[sel] = 0.0                                 # zero consensus threshold
+    elif mode == 7: x2d[sel] = np.inf
+    elif mode == 8: x3d[sel, :, 0] = 0.0; x3d[sel, :, 1] = 0.0     # collinear object
+    elif mode == 9: x3d[sel] = x3d[sel][:, :1]                     # every point the same 3-D point, different pixels
+    with np.errstate(all='ignore'):
+        ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_init=True, num_threads=0)
+    d = [dv(x2d), dv(istd), dv(x3d), dv(K), dv(ur), dv(vr), dv(thr)]
+    ini, im, iv, _, _ = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[6])
+    out = pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, im, iv, z_min=0.5, inlier_opt_only=True, with_diag=True)
+    torch.cuda.synchronize()
+    valid, pose, mask = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy(), out[4].cpu().numpy().astype(bool)
+    nobj += B
+    if not np.isfinite(pose[valid]).all():
+        bad += 1; print('trial', trial, 'mode', mode, 'non-finite pose reported valid')
+    init_ok_ref = ref[6][:, 2] != 8
+    if not np.array_equal(iv.cpu().numpy().astype(bool), init_ok_ref):
+        dd = np.flatnonzero(iv.cpu().numpy().astype(bool) != init_ok_ref)
+        print('trial', trial, 'mode', mode, 'B', B, 'P', P, 'initialiser success flag differs for', len(dd), 'objects', dd[:5]); bad += 1
+    if not np.array_equal(mask, ref[5]):
+        dd = np.flatnonzero((mask != ref[5]).any(1))
+        print('trial', trial, 'mode', mode, 'B', B, 'P', P, 'inlier mask differs for', len(dd), 'objects', dd[:5]); bad += 1
+    if not np.array_equal(valid, ref[0]):
+        dd = np.flatnonzero(valid != ref[0])
+        print('trial', trial, 'mode', mode, 'B', B, 'P', P, 'validity differs from the restatement for', len(dd), 'objects', dd[:5]); bad += 1
+print('EPnP fuzz done:', nobj, 'objects, problems:', bad)
