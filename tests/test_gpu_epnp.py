@@ -199,3 +199,38 @@ def test_empty_batch_and_argument_checks(dev):
     assert ret.shape == (0,) and yaw.shape == (0, 1) and t.shape == (0, 3) and cov.shape == (0, 4, 4) and mask.shape == (0, 784)
     with pytest.raises(ValueError):
         pnp_uncert(z(1, 784, 2), z(1, 784, 2), z(1, 784, 3), z(1, 3, 3), z(1, 2), z(1, 2), initialiser='cv2')
+
+
+def test_adversarial_inputs_terminate_and_agree_with_the_restatement(dev, orc):
+    """coincident / planar / collinear objects, NaN and Inf correspondences, overflowing coordinates, zero weights, zero thresholds
+    (tests/sweeps/gpu_epnp_fuzz.py has the 400-trial version, profiles/r03_epnp_fuzz.txt): both launches terminate, no non-finite pose is
+    reported valid, initialiser success flags and inlier masks equal the restatement's (NaN spectra included: every comparison of the
+    eigenvalue ranking is false there, and both sides then read column 0)."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        B = int(rng.choice([1, 3, 40])); hw = int(rng.choice([3, 4, 8, 10]))
+        b = syn.make_batch(B=B, hw=hw, seed=int(rng.integers(1 << 30)))
+        x2d, istd, x3d, K, ur, vr, thr = [np.array(a, copy=True) for a in syn.pnp_boundary(b, planar=bool(rng.integers(2)))]
+        P = x2d.shape[1]
+        mode, sel = trial % 10, rng.uniform(size=B) < 0.5
+        if mode == 0: x3d[sel] = 0.0
+        elif mode == 1: x2d[sel, rng.integers(P)] = np.nan
+        elif mode == 2: istd[sel] = 0.0
+        elif mode == 3: x3d[sel] *= 1e20
+        elif mode == 4: x3d[sel, :, 1] = 0.0
+        elif mode == 5: x3d[sel] = rng.normal(0, 1, x3d[sel].shape).astype(np.float32)
+        elif mode == 6: thr[sel] = 0.0
+        elif mode == 7: x2d[sel] = np.inf
+        elif mode == 8: x3d[sel, :, 0] = 0.0; x3d[sel, :, 1] = 0.0
+        elif mode == 9: x3d[sel] = x3d[sel][:, :1]
+        with np.errstate(all='ignore'):
+            ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+        d = [_t(dev, a) for a in (x2d, istd, x3d, K, ur, vr, thr)]
+        ini, im, iv, _, _ = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[6])
+        out = pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, im, iv, z_min=0.5, inlier_opt_only=True)
+        torch.cuda.synchronize()
+        valid, pose, mask = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy(), out[4].cpu().numpy().astype(bool)
+        assert np.isfinite(pose[valid]).all(), (trial, mode)
+        assert np.array_equal(iv.cpu().numpy().astype(bool), ref[6][:, 2] != 8), (trial, mode)
+        assert np.array_equal(mask, ref[5]), (trial, mode)
