@@ -129,13 +129,20 @@ int mr_pnp_uncert_batched(
  * diag (B,4) f32 or NULL [RANSAC iterations run, inliers of the best model, candidates, index of the best model],
  * debug_hypotheses (B,30,12) f64 or NULL (every hypothesis' R | t; tests).  Feed the three outputs to
  * mr_pnp_uncert_from_init_batched for the LM + covariance.
+ * The call is a sequence of launches on `stream` (sample set-up, 30 B speculative hypotheses: M^T M, 12x12 eigen-problems, poses;
+ * consensus + OpenCV's sequential loop replayed over the counts; the re-fit) that hand their intermediate results over in
+ * `workspace`: device memory of at least mr_epnp_workspace_bytes(B, P) bytes, 256-byte aligned, owned by the caller and free to be
+ * reused once the work queued on `stream` has passed it (65 MB per 1024 objects).  workspace = NULL: the library takes it from the
+ * device's default memory pool for the duration of the call (hipMallocAsync / hipFreeAsync on `stream`).
  */
 int mr_epnp_ransac_batched(
     const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
     const void *x3d, const int64_t *x3d_strides, int in_dtype,
     const float *cam_mats, int cam_batch, const float *ransac_thr, int B, int P,
     float istd_thres, int flags, int max_iters,
-    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses, void *stream);
+    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses,
+    void *workspace, size_t workspace_bytes, void *stream);
+size_t mr_epnp_workspace_bytes(int B, int P);
 
 /*
  * LM + covariance (stages 3 and 4 of mr_pnp_uncert_batched) from an EXTERNAL initialiser's result: init_mask (B,P) u8 is the

@@ -7,6 +7,9 @@
 #include <string.h>
 #include <atomic>
 #include <mutex>
+#include <map>
+#include <utility>
+#include <stdlib.h>
 #include <vector>
 #include <type_traits>
 
@@ -375,6 +378,8 @@ struct PnpArgs {
 #include "hessian_kernel.inc"
 #include "pnp_noc_kernel.inc"
 #include "epnp_kernel.inc"
+#include "epnp_eig_lanes.inc"
+#include "epnp_stages.inc"
 constexpr size_t kNocLds = sizeof(double) * (2 * 4 * kRedN + 2 * 40);     // reduction scratch + two sets of block sums
 
 // ------------------------------------------------------------------------------------------------
@@ -779,6 +784,78 @@ int launch_epnp(EpnpArgs &ea, hipStream_t st) {
     return MR_OK;
 }
 
+// opt-in to more than 64 KB of dynamic LDS, once per (kernel, device, size)
+int grant_lds(const void *fn, size_t lds) {
+    static std::mutex mu; static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &g = granted[std::make_pair(fn, dev)];
+    if (lds > g) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        g = lds;
+    }
+    return MR_OK;
+}
+
+// The staged form of the initialiser (epnp_stages.inc): eight launches on `st`, intermediate results in `workspace` (caller's, at
+// least mr_epnp_workspace_bytes(B, P)) or, when that is null, in a stream-ordered allocation of the device's default memory pool.
+template <typename T>
+int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    PnpArgs &a = ea.p;
+    a.elem_size = (int)sizeof(T);
+    a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
+    a.nca = (((a.P + 63) / 64) + 3) & ~3;
+    a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
+    const size_t lds_f = epnp_front_lds_bytes(a), lds_c = epnp_consensus_lds_bytes(a), lds_r = epnp_refit_lds_bytes(a);
+    if (lds_f > dev_info().lds_per_cu || lds_c > dev_info().lds_per_cu || lds_r > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
+    const size_t need = epnp_work_bytes(a.B, a.P, nullptr, nullptr);
+    unsigned char *base = (unsigned char *)workspace;
+    bool own = false;
+    if (base) { if (workspace_bytes < need || ((uintptr_t)base & 255)) return MR_ERR_BAD_ARGUMENT; }
+    else {
+        static std::mutex mu; static bool pool_kept[kMaxDevices] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (dev >= 0 && dev < kMaxDevices && !pool_kept[dev]) {       // keep freed blocks in the pool across synchronisations
+                hipMemPool_t pool;
+                HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+                uint64_t keep = ~0ull;
+                HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+                pool_kept[dev] = true;
+            }
+        }
+        HIP_TRY(hipMallocAsync((void **)&base, need, st));
+        own = true;
+    }
+    epnp_work_bytes(a.B, a.P, &ea.w, base);
+    int rc = MR_OK;
+    auto run = [&]() -> int {
+        int r;
+        if ((r = grant_lds((const void *)epnp_front_kernel<T>, lds_f)) != MR_OK) return r;
+        if ((r = grant_lds((const void *)epnp_consensus_kernel<T>, lds_c)) != MR_OK) return r;
+        if ((r = grant_lds((const void *)epnp_refit_kernel<T>, lds_r)) != MR_OK) return r;
+        const long long nq = ea.w.nq;
+        hipLaunchKernelGGL((epnp_front_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_f, st, ea);
+        hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, ea);
+        hipLaunchKernelGGL((epnp_eig12_kernel<2, 30>), dim3((unsigned)((nq + 29) / 30)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, nq, nq, 1LL,
+                           (const int *)(ea.w.meta + EP_M_MODE), kEpMaxIters, (int)EP_MODE_RANSAC);
+        hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
+        hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
+        hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((a.B + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
+                           (const int *)(ea.w.meta + EP_M_REFIT), 1, 1);
+        hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
+        hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
+        HIP_TRY(hipGetLastError());
+        return MR_OK;
+    };
+    rc = run();
+    if (own) { const hipError_t e = hipFreeAsync(base, st); if (rc == MR_OK && e != hipSuccess) { g_last_hip_error = (int)e; rc = MR_ERR_HIP; } }
+    return rc;
+}
+
 }  // namespace
 
 // ================================================================================= C ABI =========
@@ -888,7 +965,8 @@ int mr_epnp_ransac_batched(
     const void *x3d, const int64_t *x3d_strides, int in_dtype,
     const float *cam_mats, int cam_batch, const float *ransac_thr, int B, int P,
     float istd_thres, int flags, int max_iters,
-    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses, void *stream) {
+    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses,
+    void *workspace, size_t workspace_bytes, void *stream) {
     if (B < 0 || P < 4 || P > 64 * kMaxChunks || max_iters < 1 || max_iters > kEpMaxIters) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !init_pose || !init_mask || !init_valid)
@@ -912,12 +990,30 @@ int mr_epnp_ransac_batched(
     ea.max_iters = max_iters;
     ea.dbg_time = g_ep_time;
     hipStream_t st = (hipStream_t)stream;
+    static const bool monolithic = getenv("MR_EPNP_MONOLITHIC") != nullptr;       // development: the one-kernel form, for comparison
+    if (monolithic) {
+        switch (in_dtype) {
+            case MR_F32: return launch_epnp<float>(ea, st);
+            case MR_F16: return launch_epnp<__half>(ea, st);
+            case MR_F64: return launch_epnp<double>(ea, st);
+            default: return MR_ERR_UNSUPPORTED;
+        }
+    }
+    EpnpStageArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.p = ea.p;
+    sa.init_pose = init_pose; sa.init_mask = init_mask; sa.init_ok = init_valid; sa.diag = diag; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
     switch (in_dtype) {
-        case MR_F32: return launch_epnp<float>(ea, st);
-        case MR_F16: return launch_epnp<__half>(ea, st);
-        case MR_F64: return launch_epnp<double>(ea, st);
+        case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, st);
+        case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, st);
+        case MR_F64: return launch_epnp_stages<double>(sa, workspace, workspace_bytes, st);
         default: return MR_ERR_UNSUPPORTED;
     }
+}
+
+size_t mr_epnp_workspace_bytes(int B, int P) {
+    if (B <= 0 || P < 4) return 0;
+    return epnp_work_bytes(B, P, nullptr, nullptr);
 }
 
 int mr_cov_symeig_rule(uint8_t *valid, float *cov, int B, float *eig_min_max, void *stream) {

@@ -88,11 +88,14 @@ def epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd
     hyp = torch.zeros(B, 30, 12, device=dev, dtype=torch.float64) if debug_hypotheses else None
     if B > 0:
         with torch.cuda.device(dev):
+            # the launches of the call hand their intermediate results over in a workspace: from torch's caching allocator, on the
+            # stream the launches go to (the block returns to the allocator when `work` dies; stream order keeps that safe)
+            work = torch.empty(int(lib.mr_epnp_workspace_bytes(B, P)), device=dev, dtype=torch.uint8)
             _lib.check(lib.mr_epnp_ransac_batched(
                 x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt],
                 cam.data_ptr(), cam.shape[0], thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), int(flags), int(max_iters),
                 init_pose.data_ptr(), init_mask.data_ptr(), init_valid.data_ptr(), diag.data_ptr() if diag is not None else None,
-                hyp.data_ptr() if hyp is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+                hyp.data_ptr() if hyp is not None else None, work.data_ptr(), work.numel(), torch.cuda.current_stream(dev).cuda_stream))
     return init_pose, init_mask, init_valid, diag, hyp
 
 

@@ -224,7 +224,7 @@ def test_integration_md_cffi_block_is_the_generated_prototype_text_and_every_sym
             m = re.match(r'^(.*?)(\w+)\((.*)\);$', line)
             name, args = m.group(2), m.group(3)
             for tok in re.findall(r'[A-Za-z_]\w*', m.group(1) + ' ' + re.sub(r'\b\w+(?=\s*(,|$))', '', args)):
-                assert tok in ('const', 'void', 'int', 'float', 'double', 'char', 'uint8_t', 'int8_t', 'int32_t', 'int64_t'), (name, tok)
+                assert tok in ('const', 'void', 'int', 'float', 'double', 'char', 'uint8_t', 'int8_t', 'int32_t', 'int64_t', 'size_t'), (name, tok)
             protos.append((name, 0 if args.strip() == 'void' else args.count(',') + 1))
     from monorun_amd import _lib
     lib = ctypes.CDLL(_lib.SO)
