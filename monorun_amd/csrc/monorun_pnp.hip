@@ -842,7 +842,7 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
         hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, ea);
         hipLaunchKernelGGL((epnp_eig12_kernel<2, 30>), dim3((unsigned)((nq + 29) / 30)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, nq, nq, 1LL,
                            (const int *)(ea.w.meta + EP_M_MODE), kEpMaxIters, (int)EP_MODE_RANSAC);
-        hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
+        hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((nq + 63) / 64), 3), dim3(64), 0, st, ea);
         hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
         hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((a.B + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
                            (const int *)(ea.w.meta + EP_M_REFIT), 1, 1);
@@ -1003,6 +1003,7 @@ int mr_epnp_ransac_batched(
     memset(&sa, 0, sizeof sa);
     sa.p = ea.p;
     sa.init_pose = init_pose; sa.init_mask = init_mask; sa.init_ok = init_valid; sa.diag = diag; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
+    { static const int stop = getenv("MR_EPNP_DEBUG_STOP") ? atoi(getenv("MR_EPNP_DEBUG_STOP")) : 0; sa.dbg_stop = stop; }
     switch (in_dtype) {
         case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, st);
         case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, st);
