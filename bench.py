@@ -671,8 +671,30 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
         extra['epnp_initialiser'] = {'value': B_PER_GPU * ne / el, 'unit': 'solves/s', 'ms_per_step': el / ne * 1e3,
                                      'epnp_ransac_launch_ms': t_init / ne, 'lm_launch_ms': t_lm / ne, 'valid': int(out[0].sum().item()),
                                      'what': "pnp_uncert(..., initialiser='epnp') on batch 0: the reference's initialiser (30 EPnP hypotheses on cv::RNG subsets, "
-                                             'consensus, adaptive iteration count, EPnP re-fit) as its own launch, then the LM + covariance launch; masks and '
-                                             'poses equal the CPU restatement (tests/test_gpu_epnp.py); the CPU counterpart is cpu_baseline_epnp'}
+                                             'consensus, adaptive iteration count, EPnP re-fit) as its own sequence of launches, then the LM + covariance launch; '
+                                             'masks and poses equal the CPU restatement (tests/test_gpu_epnp.py); the CPU counterpart is cpu_baseline_epnp'}
+        # the same flow with prepared launches in flight (PnPPipeline): the stages are latency chains, several batches overlap
+        from monorun_amd import PnPEpnpLaunch, PnPPipeline
+        pipe = PnPPipeline(dev, depth=4, record_events=False)
+        nl = max(pipe.depth, 1)
+        le = [PnPEpnpLaunch(*dev_batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[i % NB][6], inlier_opt_only=True) for i in range(nl)]
+        for i in range(2 * nl):
+            pipe.submit(le[i % nl], slot=i % nl)
+        pipe.drain()
+        nf = max(8, args.steps // 2)
+        t1 = time.perf_counter()
+        for i in range(nf):
+            pipe.submit(le[i % nl], slot=i % nl)
+        pipe.drain()
+        el = time.perf_counter() - t1
+        ref = pnp_uncert_from_init_device(*dev_batches[0][:6], *epnp_ransac_device(*dev_batches[0][:4], epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[0][6])[:3],
+                                          z_min=0.5, inlier_opt_only=True)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(le[0].pose, ref[1]) and torch.equal(le[0].mask, ref[4]) and torch.equal(le[0].valid, ref[0]))
+        extra['epnp_initialiser']['in_flight'] = {'value': B_PER_GPU * nf / el, 'unit': 'solves/s', 'ms_per_step': el / nf * 1e3, 'launches_in_flight': nl, 'steps': nf,
+                                                  'distinct_batches': min(nl, NB), 'outputs_equal_the_one_at_a_time_results': same,
+                                                  'what': 'PnPEpnpLaunch objects (initialiser + LM, own workspace and outputs) submitted round-robin to PnPPipeline'}
+        del le
     except Exception as e:                                          # noqa: BLE001 — secondary figure
         extra['epnp_initialiser'] = {'error': repr(e)}
     # (f) the NOC path at B = 1024: raw head output -> pose, fused (one launch) and as two launches (K2 decode, then the PnP kernel)

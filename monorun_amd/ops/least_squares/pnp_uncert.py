@@ -200,6 +200,61 @@ class PnPLaunch:
             _lib.check(code)
 
 
+class PnPEpnpLaunch:
+    """A prepared launch of the REFERENCE's flow over device-resident inputs: its initialiser (``mr_epnp_ransac_batched``: the
+    launches of csrc/epnp_stages.inc, pnp_uncert_cpu.py:33-68) followed by the LM + covariance launch
+    (``mr_pnp_uncert_from_init_batched``) on the same stream.  Outputs, the initialiser's hand-over buffers and its workspace
+    (``mr_epnp_workspace_bytes``: 65 MB per 1024 objects) are allocated once; ``run()`` only enqueues.  The stages are latency
+    chains that leave most issue slots of the chip idle, so several of these launches in flight (``PnPPipeline.submit``)
+    overlap almost for free."""
+
+    def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=0.6,
+                 epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False):
+        self.lib = lib = _lib.load()
+        dev = coords_2d.device
+        if dev.type != 'cuda':
+            raise RuntimeError('PnPEpnpLaunch needs HIP device tensors (no CPU fallback)')
+        self.dev = dev
+        B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+        assert coords_2d.dtype in _DTYPES and coords_2d_istd.dtype == coords_2d.dtype == coords_3d.dtype
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.keep = [coords_2d, coords_2d_istd, coords_3d,
+                     cam_mats.to(**f32).reshape(-1, 3, 3).contiguous(), u_range.to(**f32).reshape(-1, 2).contiguous(),
+                     v_range.to(**f32).reshape(-1, 2).contiguous(),
+                     epnp_ransac_thres.to(**f32).reshape(-1).contiguous() if epnp_ransac_thres is not None else None]
+        x2d, istd, x3d, cam, ur, vr, thr = self.keep
+        self.init_pose = torch.empty(B, 4, device=dev, dtype=torch.float64)
+        self.init_mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+        self.init_valid = torch.empty(B, device=dev, dtype=torch.uint8)
+        self.init_diag = torch.empty(B, 4, **f32) if with_diag else None
+        self.work = torch.empty(int(lib.mr_epnp_workspace_bytes(B, P)) if B > 0 else 0, device=dev, dtype=torch.uint8)
+        self.valid = torch.empty(B, device=dev, dtype=torch.uint8)
+        self.pose = torch.empty(B, 4, **f32)
+        self.cov = torch.empty(B, 4, 4, **f32)
+        self.tr = torch.empty(B, **f32)
+        self.mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+        self.diag = torch.empty(B, 4, **f32) if with_diag else None
+        self.B = B
+        head = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[x2d.dtype], cam.data_ptr(), cam.shape[0]]
+        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), int(flags) & 0x7,
+                                 int(max_iters), self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
+                                 self.init_diag.data_ptr() if self.init_diag is not None else None, None, self.work.data_ptr(), self.work.numel()]
+        self.args_lm = head + [ur.data_ptr(), vr.data_ptr(), ur.shape[0], self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
+                               B, P, float(z_min), int(bool(inlier_opt_only)), int(flags), self.valid.data_ptr(), self.pose.data_ptr(), self.cov.data_ptr(),
+                               self.tr.data_ptr(), self.mask.data_ptr(), self.diag.data_ptr() if self.diag is not None else None]
+
+    def run(self, stream=None):
+        if self.B == 0:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):                 # the library launches on the CURRENT HIP device
+            code = self.lib.mr_epnp_ransac_batched(*self.args_init, st)
+            if not code:
+                code = self.lib.mr_pnp_uncert_from_init_batched(*self.args_lm, st)
+        if code:
+            _lib.check(code)
+
+
 class PnPPipeline:
     """Several prepared launches in flight: ``submit`` issues them round-robin on ``depth`` internal HIP streams.
 
