@@ -613,7 +613,6 @@ bool build_plan(PairwisePlan &pl, int P) {
 
 std::atomic<int> g_last_hip_error{0};
 unsigned long long *g_stamps = nullptr;
-unsigned long long *g_ep_time = nullptr;
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip_error = (int)e_; return MR_ERR_HIP; } } while (0)
 
 // What the heuristics below need to know about the device, read once per device from hipGetDeviceProperties (an MI355X reports
@@ -758,32 +757,6 @@ int launch_pnp6(Pnp6Args &a, hipStream_t st) {
     return MR_OK;
 }
 
-template <typename T>
-int launch_epnp(EpnpArgs &ea, hipStream_t st) {
-    PnpArgs &a = ea.p;
-    a.elem_size = (int)sizeof(T);
-    a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
-    a.nca = (((a.P + 63) / 64) + 3) & ~3;
-    a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
-    size_t lds = epnp_lds_bytes(a, false);
-    ea.alias_ws = 0;
-    if (lds > dev_info().lds_per_cu) { ea.alias_ws = 1; lds = epnp_lds_bytes(a, true); }      // large tiles: workspaces overlay the records
-    if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
-    {
-        static std::mutex mu; static size_t granted[kMaxDevices] = {};
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        std::lock_guard<std::mutex> lk(mu);
-        if (dev < 0 || dev >= kMaxDevices || lds > granted[dev]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)epnp_ransac_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
-        }
-    }
-    hipLaunchKernelGGL((epnp_ransac_kernel<T>), dim3(a.B), dim3(kEpThreads), lds, st, ea);
-    HIP_TRY(hipGetLastError());
-    return MR_OK;
-}
-
 // opt-in to more than 64 KB of dynamic LDS, once per (kernel, device, size)
 int grant_lds(const void *fn, size_t lds) {
     static std::mutex mu; static std::map<std::pair<const void *, int>, size_t> granted;
@@ -878,7 +851,6 @@ int mr_pnp_last_hip_error(void) { return g_last_hip_error; }
 
 // development aid (not in the public header): device buffer of (B,10) u64 cycle stamps, or NULL to disable
 void mr_pnp_debug_set_stamps(unsigned long long *dev_ptr) { g_stamps = dev_ptr; }
-void mr_epnp_debug_set_times(unsigned long long *dev_ptr) { g_ep_time = dev_ptr; }       // (B,8) phase clocks of the EPnP kernel
 
 // Occupies one wavefront of the device for `microseconds` (100 MHz constant clock).  PnPPipeline uses it to find out which of
 // its streams the runtime really runs side by side: HIP maps streams onto a small number of hardware queues (4 per priority level
@@ -972,9 +944,9 @@ int mr_epnp_ransac_batched(
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !init_pose || !init_mask || !init_valid)
         return MR_ERR_BAD_ARGUMENT;
     if (cam_batch != 1 && cam_batch != B) return MR_ERR_BAD_ARGUMENT;
-    EpnpArgs ea;
-    memset(&ea, 0, sizeof ea);
-    PnpArgs &a = ea.p;
+    EpnpStageArgs sa;
+    memset(&sa, 0, sizeof sa);
+    PnpArgs &a = sa.p;
     a.x2d = x2d; a.istd = istd; a.x3d = x3d;
     for (int i = 0; i < 3; ++i) { a.s2[i] = x2d_strides[i]; a.sw[i] = istd_strides[i]; a.s3[i] = x3d_strides[i]; }
     a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
@@ -986,24 +958,8 @@ int mr_epnp_ransac_batched(
     if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
-    ea.init_pose = init_pose; ea.init_mask = init_mask; ea.init_ok = init_valid; ea.diag = diag; ea.dbg_hyp = debug_hypotheses;
-    ea.max_iters = max_iters;
-    ea.dbg_time = g_ep_time;
-    hipStream_t st = (hipStream_t)stream;
-    static const bool monolithic = getenv("MR_EPNP_MONOLITHIC") != nullptr;       // development: the one-kernel form, for comparison
-    if (monolithic) {
-        switch (in_dtype) {
-            case MR_F32: return launch_epnp<float>(ea, st);
-            case MR_F16: return launch_epnp<__half>(ea, st);
-            case MR_F64: return launch_epnp<double>(ea, st);
-            default: return MR_ERR_UNSUPPORTED;
-        }
-    }
-    EpnpStageArgs sa;
-    memset(&sa, 0, sizeof sa);
-    sa.p = ea.p;
     sa.init_pose = init_pose; sa.init_mask = init_mask; sa.init_ok = init_valid; sa.diag = diag; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
-    { static const int stop = getenv("MR_EPNP_DEBUG_STOP") ? atoi(getenv("MR_EPNP_DEBUG_STOP")) : 0; sa.dbg_stop = stop; }
+    hipStream_t st = (hipStream_t)stream;
     switch (in_dtype) {
         case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, st);
         case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, st);

@@ -62,19 +62,4 @@ for rep in range(3):
     e[2].record()
     torch.cuda.synchronize()
     print(f'B = {B}: EPnP/RANSAC launch {e[0].elapsed_time(e[1]) * 1e3:.0f} us, LM launch {e[1].elapsed_time(e[2]) * 1e3:.0f} us')
-# phase clocks (100 MHz) of the initialiser kernel
-from monorun_amd import _lib
-import ctypes
-tm = torch.zeros(B * 24, dtype=torch.int64, device=dev)
-_lib.load().mr_epnp_debug_set_times(ctypes.c_void_p(tm.data_ptr()))
-epnp_ransac_device(dx[0], dx[1], dx[2], dx[3], epnp_istd_thres=0.6, epnp_ransac_thres=dx[6]); torch.cuda.synchronize()
-_lib.load().mr_epnp_debug_set_times(None)
-tl5 = tm[B * 8:].view(B, 16).cpu().numpy().astype(np.float64) / 100.0
-tmn = tm[:B * 8].view(B, 8).cpu().numpy().astype(np.float64) / 100.0
-d = np.diff(tmn, axis=1)
-print('phase us (median / max over objects): load+mask, subsets, hypotheses, consensus, commit+mask, refit sums, eig+candidates')
-print(np.round(np.median(d, 0), 1), np.round(d.max(0), 1))
-print('object lifetime us median', np.median(tmn[:, 7] - tmn[:, 0]), 'kernel span', (tmn[:, 7].max() - tmn[:, 0].min()))
-d5 = np.diff(tl5[:, :15], axis=1)
-print('inside one hypothesis lane (us, median): prep+pca+alphas, MtM, eig12, L/rho, betas1, betas2, betas3, [GN, pose] x3, rodrigues')
-print(np.round(np.median(d5, 0), 1))
+# per-stage times: tools/profile_epnp_quick.sh (rocprofv3 kernel trace of the initialiser's launches)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-trace summary of the EPnP / RANSAC initialiser + LM launches (development aid; run through gpurun from the repo root).
-#   [MR_EPNP_DEBUG_STOP=n] bash tools/profile_epnp_quick.sh [filter]
+#   bash tools/profile_epnp_quick.sh [filter]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/ep_trace
