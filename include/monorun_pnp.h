@@ -73,6 +73,10 @@ extern "C" {
 #define MR_DIAG_WHY           2       /* 1 gradient tol, 2 parameter tol, 3 function tol, 4 max iterations,
                                          5 min radius, 6 invalid steps (failure), 7 evaluation failure,
                                          8 initialiser failed (no LM run)                            */
+#define MR_DIAG_WHY_ILL_CONDITIONED 16 /* ADDED to the exit reason when, in some LM pass, the smallest pivot of the Jacobi-scaled damped
+                                         normal matrix fell below 1e-10 x the largest: the pose then has a direction the data do not
+                                         determine, and a Cholesky step (this library) and Ceres' DENSE_QR step on [J S; D] may return
+                                         different iterates (fixture G7b).  reason = value % 16 */
 #define MR_DIAG_K0_COUNT      3       /* consensus size of the winning hypothesis (or candidate count) */
 
 int mr_pnp_version(void);

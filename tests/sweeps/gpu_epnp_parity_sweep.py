@@ -40,7 +40,7 @@ for seed in range(100, 100 + nseeds):
     init_ok = r_diag[:, 2] != 8                       # 8 = the initialiser failed
     mm = (mask.astype(bool) != r_mask).any(1)
     di = np.abs(ini.cpu().numpy() - r_init).max(1)
-    it = diag[:, 0] != r_diag[:, 0]; wy = diag[:, 2] != r_diag[:, 2]; vv = valid.astype(bool) != r_ret
+    it = diag[:, 0] != r_diag[:, 0]; wy = diag[:, 2] % 16 != r_diag[:, 2]; vv = valid.astype(bool) != r_ret
     dp = np.maximum(np.abs(np.angle(np.exp(1j * (pose[:, 0] - r_yaw[:, 0])))), np.abs(pose[:, 1:] - r_t).max(1))
     ok = r_ret & valid.astype(bool)
     sc = np.abs(r_cov).reshape(B, -1).max(1)

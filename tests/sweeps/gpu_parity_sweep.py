@@ -30,7 +30,7 @@ for seed in range(100, 100 + nseeds):
     torch.cuda.synchronize()
     valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out]
     mm = (mask.astype(bool) != ref[5]).any(1)
-    it = diag[:, 0] != ref[6][:, 0]; wy = diag[:, 2] != ref[6][:, 2]; vv = valid.astype(bool) != ref[0]
+    it = diag[:, 0] != ref[6][:, 0]; wy = diag[:, 2] % 16 != ref[6][:, 2]; vv = valid.astype(bool) != ref[0]
     dp = np.maximum(np.abs(np.angle(np.exp(1j * (pose[:, 0] - ref[1][:, 0])))), np.abs(pose[:, 1:] - ref[2]).max(1))
     ok = ref[0] & valid.astype(bool)
     sc = np.abs(ref[3]).reshape(B, -1).max(1)

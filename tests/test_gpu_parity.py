@@ -46,7 +46,7 @@ def _cmp(gpu, ref, tag=''):
     r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag = ref
     assert np.array_equal(mask, r_mask), f'{tag}: inlier mask differs in {(mask != r_mask).sum()} points'
     assert np.array_equal(valid, r_ret), tag
-    assert np.array_equal(diag[:, 0], r_diag[:, 0]) and np.array_equal(diag[:, 2], r_diag[:, 2]), f'{tag}: LM iteration count / reason'
+    assert np.array_equal(diag[:, 0], r_diag[:, 0]) and np.array_equal(diag[:, 2] % 16, r_diag[:, 2]), f'{tag}: LM iteration count / reason'     # % 16: MR_DIAG_WHY_ILL_CONDITIONED rides on the reason
     assert np.array_equal(diag[:, 3], r_diag[:, 3]), f'{tag}: K0 consensus size'
     dyaw = np.abs(np.angle(np.exp(1j * (pose[:, 0] - r_yaw[:, 0]))))
     assert dyaw.max() <= POSE_TOL and np.abs(pose[:, 1:] - r_t).max() <= POSE_TOL, (tag, dyaw.max(), np.abs(pose[:, 1:] - r_t).max())
@@ -68,7 +68,9 @@ def test_config2_batch_matches_oracle(dev, orc, planar, wpo):
     b = syn.make_batch(B=96, seed=1234)
     x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=planar)
     ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
-    _cmp(_run(dev, x2d, istd, x3d, K, ur, vr, thr, flags=wpo << 8), ref, f'planar={planar} wpo={wpo}')
+    gpu = _run(dev, x2d, istd, x3d, K, ur, vr, thr, flags=wpo << 8)
+    _cmp(gpu, ref, f'planar={planar} wpo={wpo}')
+    assert (gpu[5][:, 2] < 16).all(), 'no object of a config-2 batch is ill-conditioned (MR_DIAG_WHY_ILL_CONDITIONED)'
 
 
 def test_given_init_pose_and_no_ransac(dev, orc, batch64):
@@ -158,10 +160,10 @@ def test_failure_paths_match(dev, orc, batch64):
     assert not ref[0][0] and not ref[0][1]
     valid, pose, cov, tr, mask, diag = gpu
     assert np.array_equal(valid, ref[0]) and np.array_equal(mask, ref[5])
-    assert np.array_equal(diag[:, 2], ref[6][:, 2])
+    assert np.array_equal(diag[:, 2] % 16, ref[6][:, 2])         # % 16: without MR_DIAG_WHY_ILL_CONDITIONED
     ok = ref[0]
     assert np.abs(pose[ok] - np.concatenate([ref[1], ref[2]], 1)[ok]).max() <= POSE_TOL
-    assert np.array_equal(pose[~ok & (diag[:, 2] == 8)], np.zeros_like(pose[~ok & (diag[:, 2] == 8)]))
+    assert np.array_equal(pose[~ok & (diag[:, 2] % 16 == 8)], np.zeros_like(pose[~ok & (diag[:, 2] % 16 == 8)]))
     bad = ~np.isfinite(ref[3]).all((1, 2))
     assert np.array_equal(np.isfinite(cov).all((1, 2)), ~bad)
     sc = np.abs(ref[3][~bad]).reshape((~bad).sum(), -1).max(1)[:, None, None]
