@@ -277,10 +277,100 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
     for (int k = 0; k < 2; ++k) { a.istd[((long long)b * 2 + k) * hw + p] = istd[k]; a.c2d[((long long)b * 2 + k) * hw + p] = c2d[k]; }
 }
 
+// Two-pixel forms of the same arithmetic for the vector kernel: every multiplication and addition of the specified sequences acts on
+// a PAIR of pixels (v_pk_mul_f32 / v_pk_add_f32: one instruction, two IEEE float32 results, each bit-identical to the scalar
+// operation), the special cases become selects after the common path.  mr_expf / mr_logf / decode_pixel_vals stay the definition.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 mr_expf2(f32x2 x) {
+#pragma clang fp contract(off)
+    f32x2 kf;
+    kf.x = rintf(x.x * 1.44269504088896341f); kf.y = rintf(x.y * 1.44269504088896341f);
+    f32x2 r = x - kf * 0.693359375f;
+    r = r - kf * -2.12194440e-4f;
+    const f32x2 z = r * r;
+    f32x2 p = 1.9875691500E-4f * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    f32x2 y = p * z + r;
+    y = y + 1.0f;
+    f32x2 o;
+    o.x = ldexpf(y.x, (int)kf.x); o.y = ldexpf(y.y, (int)kf.y);
+    o.x = x.x > 88.72283935546875f ? __int_as_float(0x7f800000) : (x.x < -103.0f ? 0.0f : o.x);
+    o.y = x.y > 88.72283935546875f ? __int_as_float(0x7f800000) : (x.y < -103.0f ? 0.0f : o.y);
+    return o;
+}
+__device__ __forceinline__ f32x2 mr_logf2(f32x2 x) {
+#pragma clang fp contract(off)
+    int e0, e1;
+    f32x2 m;
+    m.x = frexpf(x.x, &e0); m.y = frexpf(x.y, &e1);
+    const bool lo0 = m.x < 0.707106781186547524f, lo1 = m.y < 0.707106781186547524f;
+    e0 -= lo0 ? 1 : 0; e1 -= lo1 ? 1 : 0;
+    const f32x2 m2 = m + m - 1.0f, m1 = m - 1.0f;
+    m.x = lo0 ? m2.x : m1.x; m.y = lo1 ? m2.y : m1.y;
+    const f32x2 z = m * m;
+    f32x2 p = 7.0376836292E-2f * m - 1.1514610310E-1f;
+    p = p * m + 1.1676998740E-1f;
+    p = p * m - 1.2420140846E-1f;
+    p = p * m + 1.4249322787E-1f;
+    p = p * m - 1.6668057665E-1f;
+    p = p * m + 2.0000714765E-1f;
+    p = p * m - 2.4999993993E-1f;
+    p = p * m + 3.3333331174E-1f;
+    f32x2 fe;
+    fe.x = (float)e0; fe.y = (float)e1;
+    f32x2 y = m * (z * p);
+    y = y + -2.12194440e-4f * fe;
+    y = y - 0.5f * z;
+    const f32x2 zz = m + y;
+    f32x2 o = zz + 0.693359375f * fe;
+    const float inf = __int_as_float(0x7f800000), nan = __int_as_float(0x7fc00000);
+    o.x = !(x.x > 0.0f) ? (x.x == 0.0f ? -inf : nan) : (x.x == inf ? x.x : o.x);
+    o.y = !(x.y > 0.0f) ? (x.y == 0.0f ? -inf : nan) : (x.y == inf ? x.y : o.y);
+    return o;
+}
+// pixels p and p + 1 of one object row-major (p even, same row: w is even whenever h * w % 4 == 0 ... not required: px / py per pixel)
+__device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const DecodeObj &o, int p, const f32x2 (&nocv)[3], const f32x2 (&lsv)[2],
+                                                  f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3]) {
+#pragma clang fp contract(off)
+    f32x2 xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const f32x2 part = nocv[k] * o.ns[k] + o.nm[k];
+        c3d[k] = part * o.dm[k];
+        xv[k] = o.dv[k] * (part * part);
+    }
+    const f32x2 v2[2] = { 0.5f * (xv[0] + xv[2]), xv[1] };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f32x2 ls = lsv[k];
+        f32x2 lspx;
+        if (a.has_var) {
+            const f32x2 num = v2[k] * a.k_epi + mr_expf2(2.0f * ls) * a.k_sd2;
+            f32x2 q;
+            q.x = num.x / a.sd_sq; q.y = num.y / a.sd_sq;
+            lspx = 0.5f * mr_logf2(q);
+        } else lspx = ls + 0.0f;                                  // log(sd / sd)
+        const f32x2 ex = mr_expf2(-lspx);
+        istd[k].x = ex.x / a.std_scale; istd[k].y = ex.y / a.std_scale;
+    }
+    const int py0 = p / a.w, px0 = p - py0 * a.w, py1 = (p + 1) / a.w, px1 = (p + 1) - py1 * a.w;
+    f32x2 fx, fy;
+    fx.x = (float)px0; fx.y = (float)px1; fy.x = (float)py0; fy.y = (float)py1;
+    c2d[0] = (o.x1 - 0.5f) + (fx + 0.5f) * o.su;
+    c2d[1] = (o.y1 - 0.5f) + (fy + 0.5f) * o.sv;
+}
+
 // K2, vector form: one thread per FOUR consecutive RoI pixels of one object — five 16-byte loads of the selected head channels,
 // seven 16-byte stores of the decoded channels (the scalar kernel above moves 4 bytes per lane and instruction and leaves the last
 // of an object's ceil(784/256) = 4 blocks 94 % idle: 15.1 us per 1024 x 28x28 batch = 32 % of the HBM roofline).  One workgroup per
-// object (grid = B).  Same per-pixel arithmetic, hence bit-identical outputs.  Requires fp32 head output,
+// object (grid = B).  Same per-pixel arithmetic (two pixels per packed instruction), hence bit-identical outputs.  Timeline of a
+// 1024-object launch (100 MHz stamps inside the kernel): workgroups start within 0.4 us, their loads land after 3.3 - 4.2 us, the
+// arithmetic takes 3.6 - 5.9 us, the stores are acknowledged 0.3 us later: 10.0 us from the first wave to the last; rocprofv3
+// reports 13.1 us for the dispatch (its ~3 us floor for any kernel included).  The phases do not overlap because every workgroup
+// is in the same phase at the same time; packed arithmetic (-46 % instructions) bought 0.5 us.  Requires fp32 head output,
 // h*w % 4 == 0, no coord_2d map (the launcher falls back to the scalar kernel otherwise).
 template <int THREADS, int TRIPS>
 __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj) {
@@ -321,20 +411,27 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
             const int p0 = 4 * q;
             float out[7][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float noc[3] = { ((const float *)&in[t][0])[j], ((const float *)&in[t][1])[j], ((const float *)&in[t][2])[j] };
-                const float ls[2] = { ((const float *)&in[t][3])[j], ((const float *)&in[t][4])[j] };
-                float c2[2], w2[2], c3[3];
-                decode_pixel_vals(a, o, p0 + j, noc, ls, c2, w2, c3);
-                out[0][j] = c2[0]; out[1][j] = c2[1]; out[2][j] = w2[0]; out[3][j] = w2[1]; out[4][j] = c3[0]; out[5][j] = c3[1]; out[6][j] = c3[2];
+            for (int j = 0; j < 4; j += 2) {                  // pixel pairs (p0, p0 + 1), (p0 + 2, p0 + 3): packed float32 arithmetic
+                f32x2 noc[3], ls[2], c2[2], w2[2], c3[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { noc[k].x = ((const float *)&in[t][k])[j]; noc[k].y = ((const float *)&in[t][k])[j + 1]; }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { ls[k].x = ((const float *)&in[t][3 + k])[j]; ls[k].y = ((const float *)&in[t][3 + k])[j + 1]; }
+                decode_pixel_pair(a, o, p0 + j, noc, ls, c2, w2, c3);
+                out[0][j] = c2[0].x; out[0][j + 1] = c2[0].y; out[1][j] = c2[1].x; out[1][j + 1] = c2[1].y;
+                out[2][j] = w2[0].x; out[2][j + 1] = w2[0].y; out[3][j] = w2[1].x; out[3][j + 1] = w2[1].y;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { out[4 + k][j] = c3[k].x; out[4 + k][j + 1] = c3[k].y; }
             }
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            auto st4 = [](float *dst, const float (&v)[4]) { *(f32x4 *)dst = f32x4{ v[0], v[1], v[2], v[3] }; };     // (non-temporal stores: no difference, measured)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                *(float4 *)(a.c2d + ((long long)b * 2 + k) * hw + p0) = make_float4(out[k][0], out[k][1], out[k][2], out[k][3]);
-                *(float4 *)(a.istd + ((long long)b * 2 + k) * hw + p0) = make_float4(out[2 + k][0], out[2 + k][1], out[2 + k][2], out[2 + k][3]);
+                st4(a.c2d + ((long long)b * 2 + k) * hw + p0, out[k]);
+                st4(a.istd + ((long long)b * 2 + k) * hw + p0, out[2 + k]);
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *(float4 *)(a.c3d + ((long long)b * 3 + k) * hw + p0) = make_float4(out[4 + k][0], out[4 + k][1], out[4 + k][2], out[4 + k][3]);
+            for (int k = 0; k < 3; ++k) st4(a.c3d + ((long long)b * 3 + k) * hw + p0, out[4 + k]);
         }
     }
 }
