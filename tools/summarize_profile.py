@@ -108,7 +108,11 @@ summ = dict(tag=tag,
             k2_noc_decode=kernel_block('noc_k2', 'noc_decode_kernel', passes=('fetch', 'write', 'sq'), trace='noc_k2_trace', alg_bytes=B * P * 48 + B * 80),
             fused_head_to_pose=kernel_block('noc_fused', 'pnp_uncert_kernel', passes=('fetch', 'write', 'sq'), trace='noc_fused_trace',
                                             alg_bytes=B * (P * 20 + 52 + 85 + P + 64 + 24)),
-            epnp_ransac=kernel_block('epnp', 'epnp_ransac_kernel', passes=('sq', 'lds'), trace='epnp_trace'),
+            epnp_stages=dict(launches=[dict(kernel=r['Name'], calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3, min_us=float(r['MinNs']) / 1e3, max_us=float(r['MaxNs']) / 1e3)
+                                       for r in stats_rows('epnp_trace') if 'epnp_' in r['Name']],
+                             lm_launch=[dict(kernel=r['Name'], calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3) for r in stats_rows('epnp_trace') if 'pnp_uncert_kernel' in r['Name']],
+                             hypotheses_eigen=kernel_block('epnp', 'epnp_eig12_kernel<2, 30>', passes=('sq', 'lds'), trace='epnp_trace'),
+                             refit_eigen=kernel_block('epnp', 'epnp_eig12_kernel<4, 15>', passes=('sq', 'lds'), trace='epnp_trace')),
             bench_kernel_avg_us=b['roofline']['kernel_ms_avg'] * 1e3, bench_value=b['value'], bench_single_stream=b.get('single_stream', {}).get('value'))
 json.dump(summ, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
 t1 = summ['single_stream'].get('traffic')
@@ -117,8 +121,13 @@ if t1:
                                           f'(tools/profile_round.sh {tag}): the 4-waves-per-object kernel of isolated launches, what roofline.achieved is computed from',
                    in_flight_kernel=summ['in_flight'].get('traffic'))
     json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-for k in ('single_stream', 'in_flight', 'k2_noc_decode', 'fused_head_to_pose', 'epnp_ransac'):
+for k in ('single_stream', 'in_flight', 'k2_noc_decode', 'fused_head_to_pose'):
     blk = summ[k]
     print(k, 'avg us', blk.get('rocprof_kernel_avg_us'), 'calls', blk.get('rocprof_calls'), 'traffic ratio', (blk.get('traffic') or {}).get('ratio_traffic_over_algorithmic'),
           'roofline', (blk.get('hbm_roofline') or {}).get('frac'), 'derived', json.dumps(blk.get('derived')))
+ep = summ['epnp_stages']
+summ_us = sum(l['avg_us'] for l in ep['launches'])
+for l in ep['launches']:
+    print('epnp stage', l['kernel'][:70], 'avg us %.1f' % l['avg_us'])
+print('epnp stages sum us %.1f' % summ_us, 'hypotheses eigen derived', json.dumps(ep['hypotheses_eigen'].get('derived')))
 print('bench events avg us', summ['bench_kernel_avg_us'], 'value', b['value'], 'single_stream', summ['bench_single_stream'])
