@@ -234,3 +234,63 @@ def test_adversarial_inputs_terminate_and_agree_with_the_restatement(dev, orc):
         assert np.isfinite(pose[valid]).all(), (trial, mode)
         assert np.array_equal(iv.cpu().numpy().astype(bool), ref[6][:, 2] != 8), (trial, mode)
         assert np.array_equal(mask, ref[5]), (trial, mode)
+
+
+def test_workspace_contract_and_the_library_allocated_workspace(dev):
+    """mr_epnp_ransac_batched hands its intermediate results over in a workspace: the caller's (>= mr_epnp_workspace_bytes, 256-byte
+    aligned; anything smaller or misaligned is refused, nothing is launched) or, with NULL, a stream-ordered allocation of the library's
+    own — the two give bit-identical outputs, and a workspace full of garbage does not leak into the results."""
+    import ctypes
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import _strides, _DTYPES
+    lib = _lib.load()
+    assert lib.mr_epnp_workspace_bytes(0, 784) == 0 and lib.mr_epnp_workspace_bytes(4, 3) == 0
+    need = int(lib.mr_epnp_workspace_bytes(64, 784))
+    assert need > 64 * 30 * (144 + 48) * 8 and need % 256 == 0
+    assert int(lib.mr_epnp_workspace_bytes(128, 784)) > need
+    b = syn.make_batch(B=64, seed=77)
+    x2d, istd, x3d, K, ur, vr, thr = [_t(dev, a) for a in syn.pnp_boundary(b, planar=True)]
+
+    def call(work, nbytes):
+        ini = torch.full((64, 4), -7.0, device=dev, dtype=torch.float64); im = torch.full((64, 784), 9, device=dev, dtype=torch.uint8)
+        iv = torch.full((64,), 9, device=dev, dtype=torch.uint8)
+        code = lib.mr_epnp_ransac_batched(x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[x2d.dtype],
+                                          K.data_ptr(), K.shape[0], thr.data_ptr(), 64, 784, 0.6, 0, 30, ini.data_ptr(), im.data_ptr(), iv.data_ptr(), None, None,
+                                          work, nbytes, torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        return code, ini.cpu().numpy(), im.cpu().numpy(), iv.cpu().numpy()
+    garbage = torch.randint(0, 256, (need + 512,), device=dev, dtype=torch.uint8)
+    base = garbage.data_ptr() + (-garbage.data_ptr()) % 256
+    c0, ini0, im0, iv0 = call(base, need)
+    c1, ini1, im1, iv1 = call(None, 0)
+    assert c0 == 0 and c1 == 0
+    assert np.array_equal(ini0, ini1) and np.array_equal(im0, im1) and np.array_equal(iv0, iv1) and iv0.min() in (0, 1) and iv0.max() == 1
+    c2, ini2, im2, iv2 = call(base, need - 1)                      # too small
+    assert c2 != 0
+    assert (ini2 == -7.0).all() and (iv2 == 9).all()               # refused before anything was launched
+    c3, *_ = call(base + 8, need)                                  # misaligned
+    assert c3 != 0
+
+
+def test_prepared_reference_flow_launches_in_flight(dev):
+    """PnPEpnpLaunch (initialiser + LM, own workspace and outputs) submitted round-robin to PnPPipeline: the results of every launch equal
+    the one-call-at-a-time results of the same batch, also when the launches overlap on the device."""
+    from monorun_amd import PnPEpnpLaunch, PnPPipeline
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+    batches = [[_t(dev, a) for a in syn.pnp_boundary(syn.make_batch(B=256, seed=500 + i), planar=True)] for i in range(3)]
+    refs = []
+    for x in batches:
+        ini, im, iv, _, _ = epnp_ransac_device(x[0], x[1], x[2], x[3], epnp_istd_thres=0.6, epnp_ransac_thres=x[6])
+        refs.append(pnp_uncert_from_init_device(x[0], x[1], x[2], x[3], x[4], x[5], ini, im, iv, z_min=0.5, inlier_opt_only=True))
+    torch.cuda.synchronize()
+    pipe = PnPPipeline(dev, depth=3, record_events=True)
+    ls = [PnPEpnpLaunch(*x[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=x[6], inlier_opt_only=True) for x in batches]
+    for rep in range(3):
+        evs = [pipe.submit(ls[i], slot=i) for i in range(3)]
+    pipe.drain()
+    assert all(e is not None for e in evs)
+    for l, r in zip(ls, refs):
+        assert torch.equal(l.valid, r[0]) and torch.equal(l.pose, r[1]) and torch.equal(l.cov, r[2]) and torch.equal(l.tr, r[3]) and torch.equal(l.mask, r[4])
+        assert int(l.valid.sum()) > 200
+    empty = PnPEpnpLaunch(*[t[:0] if t.shape[0] == 256 else t for t in batches[0][:6]], epnp_ransac_thres=batches[0][6][:0])
+    empty.run()
