@@ -66,6 +66,10 @@ extern "C" {
 #define MR_WAVES_MASK         (0xF << MR_WAVES_SHIFT)
 #define MR_LM_MAXIT_SHIFT      16      /* bits 16..21: Ceres' max_num_iterations for the LM (0 = the default, 50; 1..63) */
 #define MR_LM_MAXIT_MASK       (0x3F << MR_LM_MAXIT_SHIFT)
+#define MR_EPNP_FIRST_ROUND_SHIFT 24   /* mr_epnp_ransac_batched, bits 24..28: hypotheses solved for EVERY object before the replayed RANSAC loop
+                                          is consulted (1..30; 0 = the default, 8); the rest are solved only for the objects whose loop still
+                                          wants iterations.  Changes the work done, never the result */
+#define MR_EPNP_FIRST_ROUND_MASK  (0x1F << MR_EPNP_FIRST_ROUND_SHIFT)
 
 /* diag[] layout (per object, 4 floats): */
 #define MR_DIAG_LM_ITERATIONS 0       /* LM loop passes executed                                  */
@@ -133,8 +137,8 @@ int mr_pnp_uncert_batched(
  * diag (B,4) f32 or NULL [RANSAC iterations run, inliers of the best model, candidates, index of the best model],
  * debug_hypotheses (B,30,12) f64 or NULL (every hypothesis' R | t; tests).  Feed the three outputs to
  * mr_pnp_uncert_from_init_batched for the LM + covariance.
- * The call is a sequence of launches on `stream` (sample set-up, 30 B speculative hypotheses: M^T M, 12x12 eigen-problems, poses;
- * consensus + OpenCV's sequential loop replayed over the counts; the re-fit) that hand their intermediate results over in
+ * The call is a sequence of launches on `stream` (sample set-up; speculative hypotheses in two rounds — MR_EPNP_FIRST_ROUND — each M^T M,
+ * 12x12 eigen-problems, poses, consensus + OpenCV's sequential loop replayed over the counts; the re-fit) that hand their intermediate results over in
  * `workspace`: device memory of at least mr_epnp_workspace_bytes(B, P) bytes, 256-byte aligned, owned by the caller and free to be
  * reused once the work queued on `stream` has passed it (65 MB per 1024 objects).  workspace = NULL: the library takes it from the
  * device's default memory pool for the duration of the call (hipMallocAsync / hipFreeAsync on `stream`).

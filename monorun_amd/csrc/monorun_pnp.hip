@@ -868,10 +868,10 @@ int grant_lds(const void *fn, size_t lds) {
     return MR_OK;
 }
 
-// The staged form of the initialiser (epnp_stages.inc): eight launches on `st`, intermediate results in `workspace` (caller's, at
+// The staged form of the initialiser (epnp_stages.inc): twelve launches on `st` (four of them idle when no object needs a second round), intermediate results in `workspace` (caller's, at
 // least mr_epnp_workspace_bytes(B, P)) or, when that is null, in a stream-ordered allocation of the device's default memory pool.
 template <typename T>
-int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_bytes, hipStream_t st) {
+int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_bytes, int first_round, hipStream_t st) {
     PnpArgs &a = ea.p;
     a.elem_size = (int)sizeof(T);
     a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
@@ -907,15 +907,30 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
         if ((r = grant_lds((const void *)epnp_front_kernel<T>, lds_f)) != MR_OK) return r;
         if ((r = grant_lds((const void *)epnp_consensus_kernel<T>, lds_c)) != MR_OK) return r;
         if ((r = grant_lds((const void *)epnp_refit_kernel<T>, lds_r)) != MR_OK) return r;
-        const long long nq = ea.w.nq;
         hipLaunchKernelGGL((epnp_front_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_f, st, ea);
-        hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, ea);
-        hipLaunchKernelGGL((epnp_eig12_kernel<2, 30>), dim3((unsigned)((nq + 29) / 30)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, nq, nq, 1LL,
-                           (const int *)(ea.w.meta + EP_M_MODE), kEpMaxIters, (int)EP_MODE_RANSAC);
-        hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((nq + 63) / 64), 3), dim3(64), 0, st, ea);
-        hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
+        // The 30 hypotheses of an object are solved in two rounds: [0, first) for every object, the rest only for the objects whose
+        // replayed loop still wants iterations after `first` (ptsetreg.cpp's adaptive bound: with few outliers it drops to a
+        // handful after the first good model — config-2 batches: 1.5 iterations on average, 8 at most).  Same results either way.
+        const int first = first_round < 1 ? 1 : (first_round > kEpMaxIters ? kEpMaxIters : first_round);
+        for (int round = 0; round < 2; ++round) {
+            ea.h0 = round == 0 ? 0 : first; ea.h1 = round == 0 ? first : kEpMaxIters;
+            const int nh = ea.h1 - ea.h0;
+            if (nh <= 0) break;
+            const long long lanes = (long long)a.B * nh;
+            const int *gate = ea.w.meta + (round == 0 ? EP_M_MODE : EP_M_PENDING);
+            const int want = round == 0 ? (int)EP_MODE_RANSAC : 1;
+            hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, ea);
+            if (lanes <= 16384)      // few matrices: four lanes per matrix (less lockstep divergence; the LDS copies are no limit)
+                hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((lanes + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
+                                   gate, kEpMaxIters, want, nh, ea.h0);
+            else
+                hipLaunchKernelGGL((epnp_eig12_kernel<2, 30>), dim3((unsigned)((lanes + 29) / 30)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
+                                   gate, kEpMaxIters, want, nh, ea.h0);
+            hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((lanes + 63) / 64), 3), dim3(64), 0, st, ea);
+            hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
+        }
         hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((a.B + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
-                           (const int *)(ea.w.meta + EP_M_REFIT), 1, 1);
+                           (const int *)(ea.w.meta + EP_M_REFIT), 1, 1, 0, 0);
         hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
         hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
         HIP_TRY(hipGetLastError());
@@ -1057,10 +1072,15 @@ int mr_epnp_ransac_batched(
     }
     sa.init_pose = init_pose; sa.init_mask = init_mask; sa.init_ok = init_valid; sa.diag = diag; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
     hipStream_t st = (hipStream_t)stream;
+    // hypotheses solved for every object before the replayed loop is consulted: MR_EPNP_FIRST_ROUND bits of `flags` (1..30), else the
+    // environment variable MR_EPNP_FIRST_ROUND, else 8
+    static const int first_env = [] { const char *e = getenv("MR_EPNP_FIRST_ROUND"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 30 ? 30 : v); }();
+    const int first_bits = (flags & MR_EPNP_FIRST_ROUND_MASK) >> MR_EPNP_FIRST_ROUND_SHIFT;
+    const int first_round = first_bits ? (first_bits > 30 ? 30 : first_bits) : first_env;
     switch (in_dtype) {
-        case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, st);
-        case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, st);
-        case MR_F64: return launch_epnp_stages<double>(sa, workspace, workspace_bytes, st);
+        case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, first_round, st);
+        case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, first_round, st);
+        case MR_F64: return launch_epnp_stages<double>(sa, workspace, workspace_bytes, first_round, st);
         default: return MR_ERR_UNSUPPORTED;
     }
 }

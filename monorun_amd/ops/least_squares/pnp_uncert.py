@@ -66,7 +66,7 @@ def pnp_uncert_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v
 
 
 def epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd_thres=1.0, epnp_ransac_thres=None, flags=0,
-                       max_iters=30, with_diag=False, debug_hypotheses=False):
+                       max_iters=30, with_diag=False, debug_hypotheses=False, first_round=None):
     """The reference's own initialiser on the GPU (``mr_epnp_ransac_batched``): cv2.solvePnPRansac(..., iterationsCount=30,
     flags=SOLVEPNP_EPNP) on the istd candidates of every object (plain EPnP without thresholds), pnp_uncert_cpu.py:33-68.
     Returns (init_pose f64 (B,4) [yaw0, t], init_mask u8 (B,P), init_valid u8 (B,), diag f32 (B,4)|None, hypotheses f64 (B,30,12)|None)."""
@@ -74,6 +74,8 @@ def epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd
     dev = coords_2d.device
     if dev.type != 'cuda':
         raise RuntimeError('monorun_amd EPnP/RANSAC runs on an MI355X only (no CPU fallback)')
+    if first_round is not None:                       # hypotheses solved for every object before the replayed loop is consulted (1..30; result-neutral)
+        flags = (int(flags) & ~(0x1F << _lib.MR_EPNP_FIRST_ROUND_SHIFT)) | (max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT)
     B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
     dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
     prep = lambda t: t.detach() if (t.dtype == dt and t.device == dev) else t.detach().to(device=dev, dtype=dt)
@@ -209,7 +211,7 @@ class PnPEpnpLaunch:
     overlap almost for free."""
 
     def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=0.6,
-                 epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False):
+                 epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False, first_round=None):
         self.lib = lib = _lib.load()
         dev = coords_2d.device
         if dev.type != 'cuda':
@@ -236,7 +238,7 @@ class PnPEpnpLaunch:
         self.diag = torch.empty(B, 4, **f32) if with_diag else None
         self.B = B
         head = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[x2d.dtype], cam.data_ptr(), cam.shape[0]]
-        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), int(flags) & 0x7,
+        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), (int(flags) & 0x7) | ((max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT) if first_round is not None else 0),
                                  int(max_iters), self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
                                  self.init_diag.data_ptr() if self.init_diag is not None else None, None, self.work.data_ptr(), self.work.numel()]
         self.args_lm = head + [ur.data_ptr(), vr.data_ptr(), ur.shape[0], self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),

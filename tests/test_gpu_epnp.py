@@ -105,6 +105,15 @@ def test_hard_objects_many_iterations_failures_and_tiny_sets(dev, orc):
     refs = _stage_reference(orc, x2d, istd, x3d, Kb, thr)
     _check_stage(gpu, refs)
     assert max(r['iters'] for r in refs[:16]) >= 20 and not any(r['ok'] for r in refs[16:20]) and all(r['n'] == 5 and r['ok'] for r in refs[20:24])
+    # The hypotheses are solved in two rounds (the first `first_round` for every object, the rest for the objects whose replayed loop
+    # still wants iterations): where the split falls changes the work, never a bit of the result — against the restatement and
+    # against each other (the default, 8, is what ran above)
+    for first in (1, 5, 19, 29, 30):
+        g = epnp_ransac_device(_t(dev, x2d), _t(dev, istd), _t(dev, x3d), _t(dev, Kb), epnp_istd_thres=0.6, epnp_ransac_thres=_t(dev, thr),
+                               with_diag=True, debug_hypotheses=True, first_round=first)
+        torch.cuda.synchronize()
+        _check_stage(g, refs)
+        assert all(torch.equal(a, c) for a, c in zip(g[:4], gpu[:4])), first
     # four points only (P = 4): fewer than the five a sample needs -> failure for every object, mask = all points
     g4 = epnp_ransac_device(_t(dev, x2d[:8, :4]), _t(dev, istd[:8, :4]), _t(dev, x3d[:8, :4]), _t(dev, K), epnp_istd_thres=0.6,
                             epnp_ransac_thres=_t(dev, thr[:8]), with_diag=True)

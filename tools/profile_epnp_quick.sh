@@ -5,13 +5,25 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/ep_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ep_trace -o t -- env REPS=10 python $R/tools/gpu_epnp_path.py > /dev/null 2>&1
-F=${1:-.} python - <<'P'
-import csv, glob, os, re
-f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/ep_trace/**/t_kernel_stats.csv', recursive=True)[0]
+python - <<'P'
+# per launch of the sequence, in issue order, averaged over the calls (a kernel that runs in both rounds appears twice)
+import csv, glob, os, collections
+f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/ep_trace/**/t_kernel_trace.csv', recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+seqs, cur = [], None
+for r in rows:
+    n = r['Kernel_Name']
+    if 'epnp_front_kernel' in n:
+        cur = []; seqs.append(cur)
+    if cur is not None and ('epnp_' in n or 'pnp_uncert_kernel' in n):
+        cur.append((n, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+seqs = [q for q in seqs if len(q) == len(seqs[-1])][2:]
 tot = 0.0
-for r in csv.DictReader(open(f)):
-    if not re.search(os.environ['F'], r['Name']): continue
-    if 'epnp' in r['Name']: tot += float(r['AverageNs']) / 1e3
-    print(f"{r['Name'][:86]:<86} calls {r['Calls']:>4} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
-print('sum of the epnp kernels: %.1f us' % tot)
+for i in range(len(seqs[0])):
+    d = [q[i][1] for q in seqs]
+    name = seqs[0][i][0].replace('(anonymous namespace)::', '').replace('void ', '')
+    print(f"{i:2d} {name[:64]:<64} avg {sum(d)/len(d):7.1f} us  min {min(d):7.1f} max {max(d):7.1f}")
+    if 'epnp_' in name: tot += sum(d) / len(d)
+span = [(q[-2][3] - q[0][2]) / 1e3 for q in seqs]
+print('sum of the initialiser kernels %.1f us; first start to last end of the initialiser %.1f us (avg of %d calls)' % (tot, sum(span) / len(span), len(seqs)))
 P
