@@ -87,6 +87,52 @@ def kernel_block(prefix, needle, passes=('fetch', 'write', 'sq', 'lds'), trace=N
     return out
 
 
+def epnp_block():
+    """the initialiser's launches in issue order (a kernel that runs in both rounds appears twice), averaged over the calls of the
+    trace, + the SQ / LDS counters of the two eigen launches (told apart by their grid size)"""
+    f = find('epnp_trace', 't_kernel_trace.csv')
+    if not f:
+        return {}
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    seqs, cur = [], None
+    for r in rows:
+        n = r['Kernel_Name']
+        if 'epnp_front_kernel' in n:
+            cur = []
+            seqs.append(cur)
+        if cur is not None and ('epnp_' in n or 'pnp_uncert_kernel' in n):
+            cur.append((n, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y', 1) or 1) if 'Grid_Size_X' in r else int(r.get('Grid_Size', 0))))
+    seqs = [q for q in seqs if len(q) == len(seqs[-1])][2:]
+    launches = []
+    for i in range(len(seqs[0])):
+        d = [q[i][1] for q in seqs]
+        launches.append(dict(position=i, kernel=seqs[0][i][0], grid_threads=seqs[0][i][2], avg_us=float(np.mean(d)), min_us=float(np.min(d)), max_us=float(np.max(d)), calls=len(d)))
+    out = dict(launches=launches, initialiser_sum_us=float(sum(l['avg_us'] for l in launches if 'epnp_' in l['kernel'])),
+               lm_launch_us=float(sum(l['avg_us'] for l in launches if 'pnp_uncert_kernel' in l['kernel'])))
+    # counters of the eigen launches: (name fragment, grid) -> block
+    eig = [l for l in launches if 'epnp_eig12_kernel' in l['kernel'] and l['avg_us'] > 20]
+    for tag, l in zip(('hypotheses_eigen', 'refit_eigen'), eig):
+        acc = collections.defaultdict(list)
+        for sub in ('epnp_sq', 'epnp_lds'):
+            g = find(sub, 'p_counter_collection.csv')
+            if not g:
+                continue
+            for r in csv.DictReader(open(g)):
+                if 'epnp_eig12_kernel' in r['Kernel_Name'] and int(r['Grid_Size']) == l['grid_threads']:
+                    acc[r['Counter_Name']].append(float(r['Counter_Value']))
+        c = {k: float(np.mean(v)) for k, v in acc.items()}
+        d = dict(kernel=l['kernel'], grid_threads=l['grid_threads'], avg_us=l['avg_us'], counters=c)
+        if c.get('SQ_WAVES'):
+            w = c['SQ_WAVES']
+            d['per_wave'] = {k: c[k] / w for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM') if k in c}
+            if 'SQ_WAVE_CYCLES' in c and 'SQ_ACTIVE_INST_ANY' in c:
+                d['active_frac_of_wave_cycles'] = c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES']
+            if c.get('SQ_LDS_IDX_ACTIVE'):
+                d['lds_bank_conflict_frac'] = c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE']
+        out[tag] = d
+    return out
+
+
 for sub, name in (('trace1', 'kernel_stats'), ('trace4', 'kernel_stats_in_flight'), ('noc_k2_trace', 'k2_kernel_stats'), ('noc_fused_trace', 'fused_kernel_stats'),
                   ('epnp_trace', 'epnp_kernel_stats')):
     f = find(sub, 't_kernel_stats.csv')
@@ -108,11 +154,7 @@ summ = dict(tag=tag,
             k2_noc_decode=kernel_block('noc_k2', 'noc_decode_kernel', passes=('fetch', 'write', 'sq'), trace='noc_k2_trace', alg_bytes=B * P * 48 + B * 80),
             fused_head_to_pose=kernel_block('noc_fused', 'pnp_uncert_kernel', passes=('fetch', 'write', 'sq'), trace='noc_fused_trace',
                                             alg_bytes=B * (P * 20 + 52 + 85 + P + 64 + 24)),
-            epnp_stages=dict(launches=[dict(kernel=r['Name'], calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3, min_us=float(r['MinNs']) / 1e3, max_us=float(r['MaxNs']) / 1e3)
-                                       for r in stats_rows('epnp_trace') if 'epnp_' in r['Name']],
-                             lm_launch=[dict(kernel=r['Name'], calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3) for r in stats_rows('epnp_trace') if 'pnp_uncert_kernel' in r['Name']],
-                             hypotheses_eigen=kernel_block('epnp', 'epnp_eig12_kernel<2, 30>', passes=('sq', 'lds'), trace='epnp_trace'),
-                             refit_eigen=kernel_block('epnp', 'epnp_eig12_kernel<4, 15>', passes=('sq', 'lds'), trace='epnp_trace')),
+            epnp_stages=epnp_block(),
             bench_kernel_avg_us=b['roofline']['kernel_ms_avg'] * 1e3, bench_value=b['value'], bench_single_stream=b.get('single_stream', {}).get('value'))
 json.dump(summ, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
 t1 = summ['single_stream'].get('traffic')
@@ -126,8 +168,7 @@ for k in ('single_stream', 'in_flight', 'k2_noc_decode', 'fused_head_to_pose'):
     print(k, 'avg us', blk.get('rocprof_kernel_avg_us'), 'calls', blk.get('rocprof_calls'), 'traffic ratio', (blk.get('traffic') or {}).get('ratio_traffic_over_algorithmic'),
           'roofline', (blk.get('hbm_roofline') or {}).get('frac'), 'derived', json.dumps(blk.get('derived')))
 ep = summ['epnp_stages']
-summ_us = sum(l['avg_us'] for l in ep['launches'])
-for l in ep['launches']:
-    print('epnp stage', l['kernel'][:70], 'avg us %.1f' % l['avg_us'])
-print('epnp stages sum us %.1f' % summ_us, 'hypotheses eigen derived', json.dumps(ep['hypotheses_eigen'].get('derived')))
+for l in ep.get('launches', []):
+    print('epnp launch %2d %-70s avg us %7.1f' % (l['position'], l['kernel'].replace('(anonymous namespace)::', '')[:70], l['avg_us']))
+print('initialiser sum us %.1f, LM launch %.1f' % (ep.get('initialiser_sum_us', 0), ep.get('lm_launch_us', 0)), 'hypotheses eigen per wave', json.dumps(ep.get('hypotheses_eigen', {}).get('per_wave')))
 print('bench events avg us', summ['bench_kernel_avg_us'], 'value', b['value'], 'single_stream', summ['bench_single_stream'])
