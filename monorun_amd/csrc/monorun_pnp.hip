@@ -849,7 +849,7 @@ int launch_pnp6(Pnp6Args &a, hipStream_t st) {
             if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
         }
     }
-    hipLaunchKernelGGL((pnp6_refine_kernel<T>), dim3(a.B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pnp6_refine_kernel<T>), dim3(a.B), dim3(kThreads6), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MR_OK;
 }
