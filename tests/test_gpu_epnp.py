@@ -26,7 +26,7 @@ def _t(dev, a):
     return d
 
 
-def _stage_reference(orc, x2d, istd, x3d, K, thr, istd_thres=0.6):
+def _stage_reference(orc, x2d, istd, x3d, K, thr, istd_thres=0.6, max_iters=30):
     """per object: candidates (pnp_uncert_cpu.py:164-168, :23-32) -> the restated solvePnPRansac with a trace of its hypotheses"""
     cand = orc.istd_inlier_mask(istd, np.float32(istd_thres))
     out = []
@@ -34,7 +34,7 @@ def _stage_reference(orc, x2d, istd, x3d, K, thr, istd_thres=0.6):
         m = cand[i] if cand[i].sum() > 4 else np.ones_like(cand[i])
         idx = np.nonzero(m)[0]
         Ki = K.reshape(-1, 9)[i if K.reshape(-1, 9).shape[0] > 1 else 0]
-        r = orc.epnp_ransac_trace(x3d[i][idx], x2d[i][idx], Ki, float(thr[i]))
+        r = orc.epnp_ransac_trace(x3d[i][idx], x2d[i][idx], Ki, float(thr[i]), max_iters=max_iters)
         full = np.zeros_like(m)
         if r['ok']:
             full[idx] = r['mask']
@@ -51,7 +51,7 @@ def _check_stage(gpu, refs):
     worst_init = 0.0
     for i, r in enumerate(refs):
         ev = r['cnt'] >= 0                                # the iterations the sequential loop really ran
-        a, c = hyp[i][ev], r['hyp'][ev]
+        a, c = hyp[i][:len(ev)][ev], r['hyp'][ev]
         both_nan = np.isnan(a) & np.isnan(c)
         assert np.all(both_nan | (np.abs(a - c) <= 1e-12 * np.maximum(1.0, np.abs(c)))), (i, 'hypotheses')
         assert np.array_equal(imask[i].astype(bool), r['full_mask']), (i, 'RANSAC inlier mask')
@@ -119,6 +119,29 @@ def test_hard_objects_many_iterations_failures_and_tiny_sets(dev, orc):
                             epnp_ransac_thres=_t(dev, thr[:8]), with_diag=True)
     torch.cuda.synchronize()
     assert not g4[2].any() and bool((g4[0] == 0).all()) and bool((g4[1] == 1).all())
+
+
+@pytest.mark.parametrize('max_iters', [1, 5, 12])
+def test_iteration_cap_below_the_default(dev, orc, max_iters):
+    """iterationsCount other than the reference's 30 (the C ABI takes 1 .. 30): the cap ends the replayed loop — also when it falls
+    inside the first round of hypotheses, on a round boundary, or inside the second round (outlier-heavy objects keep the adaptive
+    bound high, so the cap is what stops them)."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    rng = np.random.default_rng(11)
+    b = syn.make_batch(B=40, seed=99)
+    x2d, istd, x3d, K, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+    x3d = x3d.copy()
+    P = x2d.shape[1]
+    for i in range(0, 20):
+        bad = rng.random(P) < rng.uniform(0.4, 0.7)
+        x3d[i, bad] += rng.normal(0, 0.8, (int(bad.sum()), 3)).astype(np.float32)
+    refs = _stage_reference(orc, x2d, istd, x3d, K, thr, max_iters=max_iters)
+    for first in (None, 3):
+        gpu = epnp_ransac_device(_t(dev, x2d), _t(dev, istd), _t(dev, x3d), _t(dev, K), epnp_istd_thres=0.6, epnp_ransac_thres=_t(dev, thr),
+                                 max_iters=max_iters, with_diag=True, debug_hypotheses=True, first_round=first)
+        torch.cuda.synchronize()
+        _check_stage(gpu, refs)
+    assert max(r['iters'] for r in refs) == max_iters
 
 
 def test_plain_epnp_without_thresholds(dev, orc):
