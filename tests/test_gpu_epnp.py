@@ -326,3 +326,22 @@ def test_prepared_reference_flow_launches_in_flight(dev):
         assert int(l.valid.sum()) > 200
     empty = PnPEpnpLaunch(*[t[:0] if t.shape[0] == 256 else t for t in batches[0][:6]], epnp_ransac_thres=batches[0][6][:0])
     empty.run()
+
+
+def test_fp64_storage_gives_the_fp32_results(dev):
+    """fp64 correspondence tensors holding float32 values: the initialiser reads correspondences as float32 (as the reference hands
+    them to cv2), so every output equals the fp32-storage run's — both layouts, through the initialiser and the LM launch."""
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+    b = syn.make_batch(B=48, hw=12, seed=31)
+    for planar in (True, False):
+        x2d, istd, x3d, K, ur, vr, thr = [_t(dev, a) for a in syn.pnp_boundary(b, planar=planar)]
+        up = lambda t: torch.empty_strided(t.shape, t.stride(), dtype=torch.float64, device=dev).copy_(t)
+        a32 = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr, with_diag=True)
+        a64 = epnp_ransac_device(up(x2d), up(istd), up(x3d), K, epnp_istd_thres=0.6, epnp_ransac_thres=thr, with_diag=True)
+        torch.cuda.synchronize()
+        assert all(torch.equal(p, q) for p, q in zip(a32[:4], a64[:4])), planar
+        assert int(a32[2].sum()) >= 40
+        o32 = pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, *a32[:3], z_min=0.5, inlier_opt_only=True)
+        o64 = pnp_uncert_from_init_device(up(x2d), up(istd), up(x3d), K, ur, vr, *a64[:3], z_min=0.5, inlier_opt_only=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o32[0], o64[0]) and torch.equal(o32[4], o64[4]) and torch.allclose(o32[1], o64[1], rtol=0, atol=1e-6), planar
