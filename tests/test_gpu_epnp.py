@@ -326,6 +326,17 @@ def test_prepared_reference_flow_launches_in_flight(dev):
         assert int(l.valid.sum()) > 200
     empty = PnPEpnpLaunch(*[t[:0] if t.shape[0] == 256 else t for t in batches[0][:6]], epnp_ransac_thres=batches[0][6][:0])
     empty.run()
+    # the whole sequence (thirteen launches, no allocation, no host synchronisation inside) can be captured in a HIP graph and replayed
+    g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ls[0].run(); torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            ls[0].run()
+    for t in (ls[0].valid, ls[0].pose, ls[0].cov, ls[0].mask):
+        t.zero_()
+    g.replay(); torch.cuda.synchronize()
+    r = refs[0]
+    assert torch.equal(ls[0].valid, r[0]) and torch.equal(ls[0].pose, r[1]) and torch.equal(ls[0].cov, r[2]) and torch.equal(ls[0].mask, r[4])
 
 
 def test_fp64_storage_gives_the_fp32_results(dev):
