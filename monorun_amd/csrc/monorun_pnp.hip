@@ -923,15 +923,15 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, ea);
             if (lanes <= 16384)      // few matrices: four lanes per matrix (less lockstep divergence; the LDS copies are no limit)
                 hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((lanes + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
-                                   gate, kEpMaxIters, want, nh, ea.h0);
+                                   gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
             else
                 hipLaunchKernelGGL((epnp_eig12_kernel<2, 30>), dim3((unsigned)((lanes + 29) / 30)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
-                                   gate, kEpMaxIters, want, nh, ea.h0);
+                                   gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
             hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((lanes + 63) / 64), 3), dim3(64), 0, st, ea);
             hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
         }
         hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((a.B + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
-                           (const int *)(ea.w.meta + EP_M_REFIT), 1, 1, 0, 0);
+                           (const int *)(ea.w.meta + EP_M_REFIT), 1, 1, 0, 0, (const int *)nullptr);
         hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
         hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
         HIP_TRY(hipGetLastError());
