@@ -426,7 +426,8 @@ def exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range
 
 
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
-               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser='k0', cov_symeig_rule=False):
+               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser='k0', cov_symeig_rule=False,
+               epnp_first_round=None):
     """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
 
     coords_2d / coords_2d_istd (B,P,2), coords_3d (B,P,3), cam_mats (B|1,3,3), u_range / v_range (B|1,2),
@@ -437,8 +438,11 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     solver's J^T J).
     initialiser (not a reference keyword): 'k0' = this repository's deterministic consensus initialiser inside the fused kernel (one
     launch); 'epnp' = the reference's own initialiser — cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP),
-    pnp_uncert_cpu.py:33-68 — as its own launch in front of the LM (two launches; the published algorithm as DESIGN.md §5 restates
+    pnp_uncert_cpu.py:33-68 — as its own sequence of launches in front of the LM launch (the published algorithm as DESIGN.md §5 restates
     it: inlier sets, start pose and hence the returned pose are then the reference flow's, up to what OpenCV's own build would do).
+    epnp_first_round (with initialiser='epnp'; not a reference keyword): how many of the 30 speculative RANSAC hypotheses are solved for
+    every object before the replayed loop is consulted (default 8; the rest only where the loop wants them; 30 = one round, the setting
+    for outlier-heavy candidate sets one call at a time).  Never changes a result.
     cov_symeig_rule (not a reference keyword): also apply, per object, the eigenvalue test of the reference's fallback branch
     (pnp_uncert.py:77-85: keep an object only if lambda_min(h) > max(1e-6 lambda_max(h), 0), else ret_val = False and pose_cov = I).
     Default False = this kernel's own rule (an object is dropped when h has no Cholesky factorisation), which is what the
@@ -461,7 +465,7 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
             coords_2d, coords_2d_istd, coords_3d = mv(coords_2d), mv(coords_2d_istd), mv(coords_3d)
         if initialiser == 'epnp':
             ini, imask, ivalid, _, _ = epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd_thres=epnp_istd_thres,
-                                                          epnp_ransac_thres=epnp_ransac_thres)
+                                                          epnp_ransac_thres=epnp_ransac_thres, first_round=epnp_first_round)
             valid, pose, cov, _, mask, _ = pnp_uncert_from_init_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
                                                                        ini, imask, ivalid, z_min=z_min, inlier_opt_only=inlier_opt_only)
         elif initialiser == 'k0':
@@ -492,7 +496,7 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
 class PnPUncert(torch.nn.Module):
 
     def __init__(self, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, coord_istd_normalize=False,
-                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser='k0'):
+                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser='k0', epnp_first_round=None):
         """Module form (constructor keywords of the reference, pnp_uncert.py:93-99; no parameters, no buffers).
         epnp_istd_thres: a point is an istd inlier when both of its istd components reach this factor times the object's
         mean; inlier_opt_only: the LM refines on the inlier set only; coord_istd_normalize: divide the istd map by its
@@ -500,7 +504,7 @@ class PnPUncert(torch.nn.Module):
         super().__init__()
         if initialiser not in ('k0', 'epnp'):
             raise ValueError(f"initialiser must be 'k0' or 'epnp', got {initialiser!r}")
-        self.initialiser = initialiser
+        self.initialiser, self.epnp_first_round = initialiser, epnp_first_round
         self.z_min, self.epnp_istd_thres, self.inlier_opt_only = z_min, epnp_istd_thres, inlier_opt_only
         self.coord_istd_normalize, self.eps = coord_istd_normalize, eps
         self.forward_exact_hessian, self.use_6dof = forward_exact_hessian, use_6dof
@@ -512,4 +516,4 @@ class PnPUncert(torch.nn.Module):
         return pnp_uncert(coords_2d, istd, coords_3d, cam_mats, u_range, v_range, z_min=self.z_min,
                           epnp_istd_thres=self.epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres,
                           inlier_opt_only=self.inlier_opt_only, forward_exact_hessian=self.forward_exact_hessian,
-                          use_6dof=self.use_6dof, initialiser=self.initialiser)
+                          use_6dof=self.use_6dof, initialiser=self.initialiser, epnp_first_round=self.epnp_first_round)

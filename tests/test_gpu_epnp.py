@@ -231,6 +231,13 @@ def test_empty_batch_and_argument_checks(dev):
     assert ret.shape == (0,) and yaw.shape == (0, 1) and t.shape == (0, 3) and cov.shape == (0, 4, 4) and mask.shape == (0, 784)
     with pytest.raises(ValueError):
         pnp_uncert(z(1, 784, 2), z(1, 784, 2), z(1, 784, 3), z(1, 3, 3), z(1, 2), z(1, 2), initialiser='cv2')
+    # the module form passes its keywords through (epnp_first_round: result-neutral)
+    from monorun_amd.ops import build_pnp
+    b = syn.make_batch(B=24, hw=10, seed=3)
+    x = [_t(dev, a) for a in syn.pnp_boundary(b, planar=True)]
+    o8 = build_pnp(dict(type='PnPUncert', initialiser='epnp'))(*x)
+    o30 = build_pnp(dict(type='PnPUncert', initialiser='epnp', epnp_first_round=30))(*x)
+    assert all(torch.equal(p, q) for p, q in zip(o8, o30)) and int(o8[0].sum()) >= 20
 
 
 def test_adversarial_inputs_terminate_and_agree_with_the_restatement(dev, orc):
