@@ -732,6 +732,11 @@ def graph_us_per_launch(torch, fns, reps=20):
     return e0.elapsed_time(e1) * 1e3 / (reps * len(fns))
 
 
+def roof_of(nbytes, us):
+    ach = nbytes / (us * 1e-6) / 1e9
+    return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': nbytes}
+
+
 def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=3):
     """B = 1024 objects from the RAW NOC-head output (1024 x 30 x 28 x 28 fp32 = 96 MB per batch, 3 distinct resident batches =
     289 MB > the Infinity Cache) to poses: K2 alone (`noc_decode_kernel`, the one HBM-bound kernel of the path), K2 + PnP as two
@@ -764,10 +769,30 @@ def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=3):
     k2s[0].run(); pnps[0].run(); fus[0].run()
     torch.cuda.synchronize()
     same = bool(torch.equal(pnps[0].pose, fus[0].out['pose']) and torch.equal(pnps[0].mask, fus[0].out['inlier_mask_u8']))
+    # the fused launches IN FLIGHT (the product's PnPPipeline, one slot per resident head output, the waves-per-object it asks for):
+    # the regime of the headline, for the whole head -> pose path
+    from monorun_amd import PnPPipeline
+    pipe = PnPPipeline(dev, depth=n_batches, record_events=False)
+    inflight = None
+    if pipe.depth > 1:
+        fl = pipe.flags_for(B_PER_GPU, P)
+        fi = [PoseFromHeadLaunch(head, f.inputs['all_pred'], f.inputs['labels'], False, f.inputs['dim'], f.inputs['dim_var'], f.inputs['rois'],
+                                 f.inputs['cam_intrinsic'] if 'cam_intrinsic' in f.inputs else K, (syn.IMG_H, syn.IMG_W), flags=fl) for f in fus[:pipe.depth]]
+        for i in range(2 * len(fi)):
+            pipe.submit(fi[i % len(fi)], slot=i % len(fi))
+        pipe.drain()
+        nrun = 48
+        t1 = time.perf_counter()
+        for i in range(nrun):
+            pipe.submit(fi[i % len(fi)], slot=i % len(fi))
+        pipe.drain()
+        el = time.perf_counter() - t1
+        ok = bool(torch.equal(fi[0].out['pose'], fus[0].out['pose']) and torch.equal(fi[0].out['inlier_mask_u8'], fus[0].out['inlier_mask_u8']))
+        inflight = {'us_per_launch': el / nrun * 1e6, 'value': B_PER_GPU * nrun / el, 'unit': 'solves/s', 'launches_in_flight': len(fi),
+                    'outputs_equal_the_one_stream_results': ok, 'roofline': roof_of(bytes_fused, el / nrun * 1e6)}
+        del fi
 
-    def roof(nbytes, us):
-        ach = nbytes / (us * 1e-6) / 1e9
-        return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': nbytes}
+    roof = roof_of
     return {
         'k2_noc_decode': {'us_per_launch': t_k2, 'value': B_PER_GPU / (t_k2 * 1e-6), 'unit': 'objects/s', 'roofline': roof(bytes_k2, t_k2),
                           'bytes_model': '48 B per RoI pixel (5 selected head channels read, 7 decoded channels written, fp32) + per-object vectors'},
@@ -775,6 +800,7 @@ def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=3):
                        'roofline': roof(bytes_k2 + BYTES_PER_SOLVE * B_PER_GPU, t_two)},
         'fused': {'us_per_launch': t_fu, 'value': B_PER_GPU / (t_fu * 1e-6), 'unit': 'solves/s', 'roofline': roof(bytes_fused, t_fu),
                   'bytes_model': '20 B per RoI pixel read (the decoded maps never exist in HBM) + per-object inputs + pose / cov / calibrated cov / mask written'},
+        'fused_in_flight': inflight,
         'fused_equals_two_launch': same,
         'how': f'{n_batches} distinct resident head outputs ({n_batches * B_PER_GPU * 30 * P * 4 / 2**20:.0f} MiB), launches captured into one HIP graph and replayed '
                '(no host latency between kernels); one stream, so the PnP launches pay their slowest object',
