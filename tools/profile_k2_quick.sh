@@ -1,3 +1,5 @@
+#!/bin/bash
+# Kernel-trace average of K2 (noc_decode_kernel) over 60 launches on three resident head outputs (development aid; through gpurun, repo root).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/k2_trace
