@@ -130,6 +130,16 @@ def test_capi_argument_validation_without_a_gpu():
     assert call(P=8192) == -2                                 # tile does not fit the 160 KB LDS
     assert call(dtype=7) == -2
     assert lib.mr_pnp_error_string(-2).startswith(b'unsupported') and lib.mr_pnp_error_string(-99) == b'unknown error'
+    # the reference's initialiser: workspace sizing is host arithmetic, bad arguments are refused before any HIP call
+    assert lib.mr_epnp_workspace_bytes(0, 784) == 0 and lib.mr_epnp_workspace_bytes(8, 3) == 0
+    w1, w2 = lib.mr_epnp_workspace_bytes(1024, 784), lib.mr_epnp_workspace_bytes(2048, 784)
+    assert 40e6 < w1 < 80e6 and w1 % 256 == 0 and 1.9 * w1 < w2 < 2.1 * w1
+
+    def ecall(B=4, P=784, x2d=p, cam_batch=1, max_iters=30, out=p, work=None, nbytes=0):
+        return lib.mr_epnp_ransac_batched(x2d, st, p, st, p, st, 0, p, cam_batch, p, B, P, 0.6, 0, max_iters, out, p, p, None, None, work, nbytes, None)
+    assert ecall(B=0) == 0
+    assert ecall(B=-1) == -1 and ecall(P=3) == -1 and ecall(max_iters=0) == -1 and ecall(max_iters=31) == -1
+    assert ecall(x2d=None) == -1 and ecall(out=None) == -1 and ecall(cam_batch=2) == -1
     # NMS / decode entry points validate too
     assert lib.mr_nms_bev_batched(None, None, None, 0, 0, 0.1, None, None, None) == 0
     assert lib.mr_nms_bev_batched(p, p, p, 1, 4096, 0.1, p, p, None) == -2
