@@ -663,9 +663,10 @@ size_t lds_bytes(const PnpArgs &a, int wpo) {
     n += sizeof(float) * kHyp * 8;
     n += sizeof(int) * wpo * kHyp;
     n += sizeof(float) * (4 * a.nla + 4);
-    n += (size_t)8 * a.P * a.elem_size;                    // point records
-    n += 2 * sizeof(uint16_t) * ((a.P + 7) & ~7);        // candidate list + final inlier list
-    n += a.P;
+    const bool small = wpo <= 2;                           // one- and two-wave instantiations: 12-byte B records at fp32, one index list (pnp_kernel.inc)
+    n += (size_t)((small && a.elem_size == 4) ? 7 : 8) * a.P * a.elem_size;      // point records
+    n += (small ? 1 : 2) * sizeof(uint16_t) * ((a.P + 7) & ~7);                   // candidate list (+ final inlier list)
+    n += small ? sizeof(unsigned long long) * a.nca : (size_t)a.P;               // inlier mask: one bit or one byte per point
     return (n + 15) & ~(size_t)15;
 }
 
