@@ -679,7 +679,8 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
         from monorun_amd import PnPEpnpLaunch, PnPPipeline
         pipe = PnPPipeline(dev, depth=4, record_events=False)
         nl = max(pipe.depth, 1)
-        le = [PnPEpnpLaunch(*dev_batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[i % NB][6], inlier_opt_only=True) for i in range(nl)]
+        le = [PnPEpnpLaunch(*dev_batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[i % NB][6], inlier_opt_only=True,
+                            flags=pipe.flags_for(B_PER_GPU, P)) for i in range(nl)]       # the LM launch with the waves per object the pipeline asks for
         for i in range(2 * nl):
             pipe.submit(le[i % nl], slot=i % nl)
         pipe.drain()

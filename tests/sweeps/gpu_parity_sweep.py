@@ -1,5 +1,6 @@
 """Parity sweep over many seeds: counts objects that deviate from the oracle.
     NSEEDS=200 python tests/sweeps/gpu_parity_sweep.py                    # config-2 shape: 1024 objects x 28x28 per seed
+    WPO=2 NSEEDS=200 python tests/sweeps/gpu_parity_sweep.py              # the two-waves-per-object instantiation (what launches in flight run)
     HW=56 B=512 NSEEDS=16 python tests/sweeps/gpu_parity_sweep.py         # config-5 shape (3136 points: multi-trip loops, 66 KB tiles); odd seeds store fp16
 """
 import sys, os
@@ -26,7 +27,8 @@ for seed in range(100, 100 + nseeds):
         x2d, istd, x3d = keep(x2d), keep(istd), keep(x3d)
     ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=nthr)
     h = (lambda t: t.to(torch.float16)) if half else (lambda t: t)
-    out = pnp_uncert_device(h(dv(x2d)), h(dv(istd)), h(dv(x3d)), dv(K), dv(ur), dv(vr), 0.5, 0.6, dv(thr), True, with_diag=True)
+    out = pnp_uncert_device(h(dv(x2d)), h(dv(istd)), h(dv(x3d)), dv(K), dv(ur), dv(vr), 0.5, 0.6, dv(thr), True, with_diag=True,
+                            flags=int(os.environ.get('WPO', 0)) << 8)       # WPO: waves per object (0 = the library's choice; 1 / 2 = the packed-tile instantiations)
     torch.cuda.synchronize()
     valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out]
     mm = (mask.astype(bool) != ref[5]).any(1)

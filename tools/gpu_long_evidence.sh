@@ -2,12 +2,15 @@
 # The long evidence runs of a round (through gpurun, from the repo root): million-object parity sweeps of both flows, long fuzz
 # runs, and the spread of the bench line over repeated runs.  Outputs under gpurun_out/ (copy what is to be kept into profiles/).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=${TAG:-r03}
+PARTS=${PARTS:-k0 epnp k0_56 fuzz fuzz_epnp repeats}      # which runs; WPO=n (waves per object) is passed through to the K0 sweeps, SUFFIX names their files
 cd $R
-NSEEDS=${NSEEDS:-1000} python tests/sweeps/gpu_parity_sweep.py > $O/${T}_gpu_parity_sweep_1M.txt 2>&1; tail -1 $O/${T}_gpu_parity_sweep_1M.txt
-NSEEDS=${NSEEDS:-1000} python tests/sweeps/gpu_epnp_parity_sweep.py > $O/${T}_gpu_epnp_parity_sweep_1M.txt 2>&1; tail -2 $O/${T}_gpu_epnp_parity_sweep_1M.txt
-HW=56 B=512 NSEEDS=64 python tests/sweeps/gpu_parity_sweep.py > $O/${T}_gpu_parity_sweep_56x56_long.txt 2>&1; tail -1 $O/${T}_gpu_parity_sweep_56x56_long.txt
-TRIALS=${TRIALS:-2000} python tests/sweeps/gpu_fuzz.py > $O/${T}_fuzz_long.txt 2>&1; tail -1 $O/${T}_fuzz_long.txt
-TRIALS=${TRIALS:-2000} python tests/sweeps/gpu_epnp_fuzz.py > $O/${T}_epnp_fuzz_long.txt 2>&1; tail -2 $O/${T}_epnp_fuzz_long.txt
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+has k0 && { NSEEDS=${NSEEDS:-1000} python tests/sweeps/gpu_parity_sweep.py > $O/${T}_gpu_parity_sweep_1M${SUFFIX:-}.txt 2>&1; tail -1 $O/${T}_gpu_parity_sweep_1M${SUFFIX:-}.txt; }
+has epnp && { NSEEDS=${NSEEDS:-1000} python tests/sweeps/gpu_epnp_parity_sweep.py > $O/${T}_gpu_epnp_parity_sweep_1M.txt 2>&1; tail -2 $O/${T}_gpu_epnp_parity_sweep_1M.txt; }
+has k0_56 && { HW=56 B=512 NSEEDS=64 python tests/sweeps/gpu_parity_sweep.py > $O/${T}_gpu_parity_sweep_56x56_long${SUFFIX:-}.txt 2>&1; tail -1 $O/${T}_gpu_parity_sweep_56x56_long${SUFFIX:-}.txt; }
+has fuzz && { TRIALS=${TRIALS:-2000} python tests/sweeps/gpu_fuzz.py > $O/${T}_fuzz_long.txt 2>&1; tail -1 $O/${T}_fuzz_long.txt; }
+has fuzz_epnp && { TRIALS=${TRIALS:-2000} python tests/sweeps/gpu_epnp_fuzz.py > $O/${T}_epnp_fuzz_long.txt 2>&1; tail -2 $O/${T}_epnp_fuzz_long.txt; }
+has repeats || exit 0
 : > $O/${T}_bench_repeats.txt
 for i in $(seq 1 ${REPEATS:-12}); do
     python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
