@@ -426,3 +426,27 @@ def test_pipelined_launches_equal_isolated_launches(dev):
         for l, r, sm in zip(ls, ref, sums):
             assert torch.equal(l.pose, r.pose) and torch.equal(l.cov, r.cov) and torch.equal(l.valid, r.valid) and torch.equal(l.mask, r.mask)
             assert float(sm) == float(r.pose.double().sum())
+
+
+@pytest.mark.gpu
+def test_fused_path_with_one_and_two_waves_per_object(dev, g3):
+    """The one- and two-wave instantiations keep a packed tile in LDS (12-byte B records, one index list, a bit mask: six objects per CU
+    at P = 784): the fused head -> pose launch through them gives the inlier masks, validity and dims of the four-wave launch bit for bit
+    and its poses / covariances to summation-order noise."""
+    from monorun_amd.pose_head import pnp_from_head
+    rng = np.random.default_rng(9)
+    B = g3['all_pred'].shape[0]
+    rois = np.stack([rng.uniform(100, 900, B), rng.uniform(50, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(30, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    K = t(syn.KITTI_K[None].astype(np.float32))
+    img = np.array([[375.0, 1242.0]], np.float32)
+    args = (t(g3['all_pred']), t(g3['labels']), t(g3['flip']), t(g3['dim']), t(g3['dim_var']), t(rois), K, img)
+    ref = pnp_from_head(*args, with_diag=True, flags=4 << 8)
+    for wpo in (1, 2):
+        out = pnp_from_head(*args, with_diag=True, flags=wpo << 8)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[4], ref[4]) and torch.equal(out[5], ref[5]), wpo       # valid, inlier mask, dims
+        ok = ref[0]
+        assert torch.allclose(out[1][ok], ref[1][ok], rtol=0, atol=1e-5) and torch.allclose(out[2][ok], ref[2][ok], rtol=1e-6, atol=1e-5), wpo
+        assert torch.allclose(out[3][ok], ref[3][ok], rtol=1e-4, atol=1e-9), wpo
