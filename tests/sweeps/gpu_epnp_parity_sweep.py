@@ -33,7 +33,8 @@ for seed in range(100, 100 + nseeds):
     d = [h(dv(x2d)), h(dv(istd)), h(dv(x3d)), dv(K), dv(ur), dv(vr), dv(thr)]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ini, im, iv, _, _ = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[6])
-    out = pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, im, iv, z_min=0.5, inlier_opt_only=True, with_diag=True)
+    out = pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, im, iv, z_min=0.5, inlier_opt_only=True, with_diag=True,
+                                      flags=int(os.environ.get('WPO', 0)) << 8)      # WPO: waves per object of the LM launch (0 = the library's choice)
     torch.cuda.synchronize(); t_gpu += time.perf_counter() - t0
     valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out]
     r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag, r_init = ref
