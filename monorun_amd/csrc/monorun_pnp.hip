@@ -371,7 +371,9 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // arithmetic takes 3.6 - 5.9 us, the stores are acknowledged 0.3 us later: 10.0 us from the first wave to the last; rocprofv3
 // reports 13.1 us for the dispatch (its ~3 us floor for any kernel included).  The phases do not overlap because every workgroup
 // is in the same phase at the same time; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us; starting the waves that share
-// a SIMD 0.2 - 0.8 us apart (s_sleep by hardware wave slot) changed nothing (13.5 - 14.4 us, inside the run-to-run spread).  Requires fp32 head output,
+// a SIMD 0.2 - 0.8 us apart (s_sleep by hardware wave slot) changed nothing (13.5 - 14.4 us, inside the run-to-run spread); nor did issuing
+// the pixel loads right behind label + flip, ahead of the object's other parameters (decode_object compiles to five dependent rounds of
+// scalar loads: 13.5 us either way — the pixel data is late because 16 MB are asked for at once, not because of the prologue).  Requires fp32 head output,
 // h*w % 4 == 0, no coord_2d map (the launcher falls back to the scalar kernel otherwise).
 template <int THREADS, int TRIPS>
 __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj) {
