@@ -332,8 +332,15 @@ __device__ __forceinline__ f32x2 mr_logf2(f32x2 x) {
     return o;
 }
 // pixels p and p + 1 of one object row-major (p even, same row: w is even whenever h * w % 4 == 0 ... not required: px / py per pixel)
+// x / c for a wave-uniform float32 c, correctly rounded like the IEEE division it replaces, in 3 instructions instead of ~12: the
+// quotient is formed in float64 as x * RN64(1 / c) (relative error < 2^-52) and rounded to float32 once.  A float32 quotient of two
+// float32 numbers is never closer than 2^-49 (relative) to a rounding boundary — with X, C the 24-bit significands and M the odd 25-bit
+// significand of a midpoint, X 2^s - M C is a non-zero integer — so that single rounding lands on the IEEE result; zeros, infinities,
+// NaNs, c = 0, overflow and float32 denormals go through the float64 product and the conversion unchanged.  rc = 1.0 / (double)c.
+__device__ __forceinline__ float div_by_uniform(float x, double rc) { return (float)((double)x * rc); }
+
 __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const DecodeObj &o, int p, const f32x2 (&nocv)[3], const f32x2 (&lsv)[2],
-                                                  f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3]) {
+                                                  f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3], double rc_sd_sq, double rc_std_scale) {
 #pragma clang fp contract(off)
     f32x2 xv[3];
 #pragma unroll
@@ -350,11 +357,11 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
         if (a.has_var) {
             const f32x2 num = v2[k] * a.k_epi + mr_expf2(2.0f * ls) * a.k_sd2;
             f32x2 q;
-            q.x = num.x / a.sd_sq; q.y = num.y / a.sd_sq;
+            q.x = div_by_uniform(num.x, rc_sd_sq); q.y = div_by_uniform(num.y, rc_sd_sq);
             lspx = 0.5f * mr_logf2(q);
         } else lspx = ls + 0.0f;                                  // log(sd / sd)
         const f32x2 ex = mr_expf2(-lspx);
-        istd[k].x = ex.x / a.std_scale; istd[k].y = ex.y / a.std_scale;
+        istd[k].x = div_by_uniform(ex.x, rc_std_scale); istd[k].y = div_by_uniform(ex.y, rc_std_scale);
     }
     const int py0 = p / a.w, px0 = p - py0 * a.w, py1 = (p + 1) / a.w, px1 = (p + 1) - py1 * a.w;
     f32x2 fx, fy;
@@ -370,7 +377,8 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // 1024-object launch (100 MHz stamps inside the kernel): workgroups start within 0.4 us, their loads land after 3.3 - 4.2 us, the
 // arithmetic takes 3.6 - 5.9 us, the stores are acknowledged 0.3 us later: 10.0 us from the first wave to the last; rocprofv3
 // reports 13.1 us for the dispatch (its ~3 us floor for any kernel included).  The phases do not overlap because every workgroup
-// is in the same phase at the same time; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us; starting the waves that share
+// is in the same phase at the same time; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us, div_by_uniform (16 IEEE divisions
+// per lane -> 16 float64 products) another 0.3 - 0.5 us (12.9 us); starting the waves that share
 // a SIMD 0.2 - 0.8 us apart (s_sleep by hardware wave slot) changed nothing (13.5 - 14.4 us, inside the run-to-run spread); nor did issuing
 // the pixel loads right behind label + flip, ahead of the object's other parameters (decode_object compiles to five dependent rounds of
 // scalar loads: 13.5 us either way — the pixel data is late because 16 MB are asked for at once, not because of the prologue).  Requires fp32 head output,
@@ -395,6 +403,7 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
         if (a.thr) a.thr[b] = o.thr;
     }
     const float *ap = (const float *)a.all_pred;
+    const double rc_sd_sq = 1.0 / (double)a.sd_sq, rc_std_scale = 1.0 / (double)a.std_scale;      // div_by_uniform
     for (int q0 = threadIdx.x; q0 < quads_per_obj; q0 += THREADS * TRIPS) {
         float4 in[TRIPS][5];
 #pragma unroll
@@ -420,7 +429,7 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 for (int k = 0; k < 3; ++k) { noc[k].x = ((const float *)&in[t][k])[j]; noc[k].y = ((const float *)&in[t][k])[j + 1]; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) { ls[k].x = ((const float *)&in[t][3 + k])[j]; ls[k].y = ((const float *)&in[t][3 + k])[j + 1]; }
-                decode_pixel_pair(a, o, p0 + j, noc, ls, c2, w2, c3);
+                decode_pixel_pair(a, o, p0 + j, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale);
                 out[0][j] = c2[0].x; out[0][j + 1] = c2[0].y; out[1][j] = c2[1].x; out[1][j + 1] = c2[1].y;
                 out[2][j] = w2[0].x; out[2][j + 1] = w2[0].y; out[3][j] = w2[1].x; out[3][j + 1] = w2[1].y;
 #pragma unroll
