@@ -450,3 +450,36 @@ def test_fused_path_with_one_and_two_waves_per_object(dev, g3):
         ok = ref[0]
         assert torch.allclose(out[1][ok], ref[1][ok], rtol=0, atol=1e-5) and torch.allclose(out[2][ok], ref[2][ok], rtol=1e-6, atol=1e-5), wpo
         assert torch.allclose(out[3][ok], ref[3][ok], rtol=1e-4, atol=1e-9), wpo
+
+
+@pytest.mark.gpu
+def test_k2_special_inputs_take_the_exact_path(dev, g3, orc):
+    """The special cases of the specified exp / log sequences in the vector decode kernel (packed two-pixel forms with selects): log-std
+    values beyond the exp range, infinities, NaNs, non-positive variances planted in a few pixels of otherwise ordinary objects decode
+    exactly as the specification (oracle) says."""
+    from monorun_amd.pose_head import noc_decode
+    rng = np.random.default_rng(11)
+    pred = np.array(g3['all_pred'], np.float32, copy=True)
+    B, C, H, W = pred.shape
+    plant = np.float32([45.0, 60.0, 100.0, 200.0, -45.0, -52.0, -60.0, -200.0, 88.0, -88.0, np.inf, -np.inf, np.nan, 3e38, -3e38, 1e-40])
+    for b in range(0, B, 2):                                  # every second object: a handful of pixels in every log-std channel
+        for c in range(C):
+            for v in plant[rng.integers(0, len(plant), 3)]:
+                pred[b, c, rng.integers(0, H), rng.integers(0, W)] = v
+    rois = np.stack([rng.uniform(0, 900, B), rng.uniform(0, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(20, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    dec = noc_decode(t(pred), t(g3['labels']), t(g3['flip']), t(g3['dim']), t(g3['dim_var']), t(rois))
+    torch.cuda.synchronize()
+    with np.errstate(all='ignore'):
+        n_noc, n_ls, _ = orc.slice_pred(pred, g3['labels'], g3['flip'])
+        d_, dv_ = orc.dim_decode(g3['dim'], g3['dim_var'], g3['labels'])
+        c3d_ref, var_ref = orc.noc_decode(n_noc, d_, dv_)
+        ls_spec = orc.decode_logstd(n_ls, var_ref, exp=orc.spec_expf, log=orc.spec_logf)
+        istd_ref = orc.spec_expf(-ls_spec) / np.float32(10)
+    got = dec['coords_2d_istd'].cpu().numpy()
+    same = (got.view(np.uint32) == istd_ref.view(np.uint32)) | (np.isnan(got) & np.isnan(istd_ref))
+    assert same.all(), f'{(~same).sum()} decoded istd values differ from the specification on special inputs'
+    assert (~np.isfinite(got)).sum() > 0 and (got == 0).sum() > 0, 'the planted values did not reach the special cases'
+    c3d = dec['coords_3d'].cpu().numpy()
+    assert ((c3d.view(np.uint32) == c3d_ref.view(np.uint32)) | (np.isnan(c3d) & np.isnan(c3d_ref))).all()
