@@ -379,7 +379,8 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // reports 13.1 us for the dispatch (its ~3 us floor for any kernel included).  The phases do not overlap because every workgroup
 // is in the same phase at the same time; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us, div_by_uniform (16 IEEE divisions
 // per lane -> 16 float64 products) another 0.3 - 0.5 us (12.9 us); running the exp / log sequences without their range tests and selects
-// (-80 VALU instructions per wave; a wave redoes its pixels when a lane meets a special input) nothing (12.9 us); starting the waves that share
+// (-80 VALU instructions per wave; a wave redoes its pixels when a lane meets a special input) nothing (12.9 us), and neither did a four-pixel
+// vector form whose Horner chains interleave (s_nop between dependent packed operations 194 -> 38; 12.9 - 13.8 us); starting the waves that share
 // a SIMD 0.2 - 0.8 us apart (s_sleep by hardware wave slot) changed nothing (13.5 - 14.4 us, inside the run-to-run spread); nor did issuing
 // the pixel loads right behind label + flip, ahead of the object's other parameters (decode_object compiles to five dependent rounds of
 // scalar loads: 13.5 us either way — the pixel data is late because 16 MB are asked for at once, not because of the prologue).  Requires fp32 head output,
