@@ -431,7 +431,11 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 for (int k = 0; k < 3; ++k) { noc[k].x = ((const float *)&in[t][k])[j]; noc[k].y = ((const float *)&in[t][k])[j + 1]; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) { ls[k].x = ((const float *)&in[t][3 + k])[j]; ls[k].y = ((const float *)&in[t][3 + k])[j + 1]; }
+#ifdef MR_K2_COPY_ONLY      // ubench: the kernel's memory traffic without its arithmetic (tools/profile_k2_quick.sh on a variant build)
+                c2[0] = noc[0]; c2[1] = noc[1]; w2[0] = ls[0]; w2[1] = ls[1]; c3[0] = noc[2]; c3[1] = noc[0] + ls[0]; c3[2] = noc[1] + ls[1];
+#else
                 decode_pixel_pair(a, o, p0 + j, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale);
+#endif
                 out[0][j] = c2[0].x; out[0][j + 1] = c2[0].y; out[1][j] = c2[1].x; out[1][j + 1] = c2[1].y;
                 out[2][j] = w2[0].x; out[2][j + 1] = w2[0].y; out[3][j] = w2[1].x; out[3][j + 1] = w2[1].y;
 #pragma unroll
