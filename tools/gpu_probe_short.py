@@ -10,7 +10,7 @@ def dv(a):
 NB, S = 12, 24
 batches = [[dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=1234 + 7919 * i), planar=True)] for i in range(NB)]
 tag = os.environ.get('MR_PNP_SO', 'default').split('/')[-1]
-for waves, depth in ((2, 4), (0, 1)):
+for waves, depth in [tuple(int(v) for v in w.split(":")) for w in os.environ.get("CASES", "2:4,0:1").split(",")]:
     ls = [[PnPLaunch(*b[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=b[6], inlier_opt_only=True, flags=(waves << 8)) for b in batches] for _ in range(S)]
     pipe = PnPPipeline(dev, depth=depth)
     for steps in (20, 480):
