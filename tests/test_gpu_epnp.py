@@ -363,3 +363,25 @@ def test_fp64_storage_gives_the_fp32_results(dev):
         o64 = pnp_uncert_from_init_device(up(x2d), up(istd), up(x3d), K, ur, vr, *a64[:3], z_min=0.5, inlier_opt_only=True)
         torch.cuda.synchronize()
         assert torch.equal(o32[0], o64[0]) and torch.equal(o32[4], o64[4]) and torch.allclose(o32[1], o64[1], rtol=0, atol=1e-6), planar
+
+
+def test_reference_flow_on_more_than_65535_objects_in_one_call(dev):
+    """One call over 73 728 objects (no grid dimension of the initialiser's launches is limited to 65 535 workgroups; a 5.3 GB workspace):
+    initial poses, RANSAC masks, final poses and masks of every object equal those of 1 024-object calls on the same data (the covariance to
+    float32 summation order: the LM launch picks its waves per object by batch size)."""
+    from monorun_amd import PnPEpnpLaunch
+    parts = [[torch.from_numpy(np.asarray(a)).to(dev) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=900 + i), planar=False)] for i in range(4)]
+    small = [PnPEpnpLaunch(*b[:6], epnp_ransac_thres=b[6], inlier_opt_only=True) for b in parts]
+    for l in small:
+        l.run()
+    reps = 18                                                      # 4 x 18 x 1024 = 73 728 objects
+    cat = lambda j: torch.cat([parts[i % 4][j] for i in range(4 * reps)], 0)
+    big = PnPEpnpLaunch(cat(0), cat(1), cat(2), parts[0][3], parts[0][4], parts[0][5], epnp_ransac_thres=cat(6), inlier_opt_only=True)
+    big.run()
+    torch.cuda.synchronize()
+    assert big.pose.shape[0] == 73728 and int(big.valid.sum()) > 70000
+    for i in range(4 * reps):
+        s, l = slice(1024 * i, 1024 * (i + 1)), small[i % 4]
+        for n in ('init_pose', 'init_mask', 'init_valid', 'pose', 'mask', 'valid'):
+            assert torch.equal(getattr(big, n)[s], getattr(l, n)), (i, n)
+        assert torch.allclose(big.cov[s], l.cov, rtol=1e-5, atol=0.0), i
