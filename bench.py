@@ -524,6 +524,11 @@ def run(args):
                        'parallelism': f'objects sharded x{world}' + (f', 1 all-gather of 88 B/object x {comm["steps_per_collective"]} step(s) per collective' if (world > 1 and comm) else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
+                         'measured_on': ('HIP events around ISOLATED launches on one stream (the library\'s own choice there: 4 waves per object), rotating over the '
+                                         'batches, in this run; rocprofv3 of `bench.py --in-flight 1` agrees (profiles/rNN_kernel_stats.csv).  With launches in flight the '
+                                         'timed region runs the 2-waves-per-object instantiation of the same kernel, several launches overlapping: a per-launch '
+                                         'duration there (~100 us each, profiles/rNN_kernel_stats_in_flight.csv) measures the overlap, not the kernel — the chip-level '
+                                         'rate of the timed region is `in_flight`') if L > 1 else 'HIP events around the launches of the timed loop\'s kernel on its stream',
                          'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)),
                          'kernel_ms_per_batch': per_batch_ms,
                          'batch0_only': {'kernel_ms': per_batch_ms[0], 'frac': BYTES_PER_SOLVE * B_PER_GPU / (per_batch_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
