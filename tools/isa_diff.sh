@@ -5,7 +5,7 @@
 # kernel the headline is measured on: the register allocation of this kernel reacts to almost anything.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-REV=$1; FRAG=${2:-pnp_uncert_kernelIfLi4E}; NEWFRAG=${3:-$FRAG}      # third argument: the fragment in the CURRENT build when the mangled name changed
+REV=$1; FRAG=${2:-pnp_uncert_kernelIfLi4ELb0E}; NEWFRAG=${3:-$FRAG}      # third argument: the fragment in the CURRENT build when the mangled name changed
 T=$(mktemp -d)
 mkdir -p $T/old
 for f in monorun_pnp.hip pnp_kernel.inc pnp6_kernel.inc pnp_noc_kernel.inc kitti_eval_kernel.inc hessian_kernel.inc epnp_kernel.inc epnp_eig_lanes.inc epnp_stages.inc; do
