@@ -493,7 +493,7 @@ struct PnpArgs {
 #include "hessian_kernel.inc"
 #include "pnp_noc_kernel.inc"
 #include "epnp_kernel.inc"
-#include "epnp_eig_lanes.inc"
+#include "epnp_eig_low4.inc"
 #include "epnp_stages.inc"
 constexpr size_t kNocLds = sizeof(double) * (2 * 4 * kRedN + 2 * 40);     // reduction scratch + two sets of block sums
 
@@ -939,22 +939,13 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             const int *gate = ea.w.meta + (round == 0 ? EP_M_MODE : EP_M_PENDING);
             const int want = round == 0 ? (int)EP_MODE_RANSAC : 1;
             hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, ea);
-            // few matrices: four lanes per matrix (less lockstep divergence; the LDS copies are no limit).  Up to one wave per SIMD
-            // of 8 matrices each: a wave's matrices iterate in lockstep (max over the wave's trip counts), and a SIMD with one wave runs it
-            // at full speed — 8 192 matrices: 164 us against 188 (15 per wave, half the SIMDs idle), 183 / 191 / 206 at 10 / 4 / 6 per wave
-            if (lanes <= 8LL * dev_info().cus * kSimdsPerCu)
-                hipLaunchKernelGGL((epnp_eig12_kernel<4, 8>), dim3((unsigned)((lanes + 7) / 8)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
-                                   gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
-            else if (lanes <= 16384)
-                hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((lanes + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
-                                   gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
-            else
-                hipLaunchKernelGGL((epnp_eig12_kernel<2, 30>), dim3((unsigned)((lanes + 29) / 30)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
-                                   gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
+            // one quad per matrix, 16 matrices per wave (fixed trip counts: nothing to gain from fewer matrices per wave)
+            hipLaunchKernelGGL((epnp_eig12_kernel<16>), dim3((unsigned)((lanes + 15) / 16)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
+                               gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
             hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((lanes + 63) / 64), 3), dim3(64), 0, st, ea);
             hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
         }
-        hipLaunchKernelGGL((epnp_eig12_kernel<4, 15>), dim3((unsigned)((a.B + 14) / 15)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
+        hipLaunchKernelGGL((epnp_eig12_kernel<16>), dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
                            (const int *)(ea.w.meta + EP_M_REFIT), 1, 1, 0, 0, (const int *)nullptr);
         hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
         hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);

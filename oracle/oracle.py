@@ -298,9 +298,20 @@ def eig12(A):
     return w, vt
 
 
-def set_epnp_eig_mode(jacobi):
-    """jacobi=True: EPnP uses the cyclic Jacobi eigen-solver for M^T M (cross-check of the tests); False: the specification (eig12)."""
-    lib().orc_set_epnp_eig_mode(ctypes.c_int(1 if jacobi else 0))
+def eig12_low4(A):
+    """The specification's solver since round 4 (epnp.inc::epnp_eig12_low4): the four smallest eigenvalues (ascending) of the
+    symmetric 12 x 12 A and their eigenvectors (rows of v4) — tridiagonalisation, bisection, inverse iteration, back-transformation."""
+    A = _d(A)
+    assert A.shape == (12, 12)
+    w4, v4 = np.zeros(4), np.zeros((4, 12))
+    lib().orc_eig12_low4(_p(A, c_dp), _p(w4, c_dp), _p(v4, c_dp))
+    return w4, v4
+
+
+def set_epnp_eig_mode(mode):
+    """Which eigen-solver EPnP uses for M^T M: 0 / False = the specification (eig12_low4); 1 / True = cyclic Jacobi, 2 = round 3's
+    Householder + implicit QL (eig12) — complete decompositions, kept as cross-checks of the tests."""
+    lib().orc_set_epnp_eig_mode(ctypes.c_int(int(mode)))
 
 
 def svd_small(A):

@@ -46,10 +46,44 @@ def test_linear_algebra_kernels_against_numpy(orc):
         assert np.all(np.diff(w) <= 0)
 
 
-def test_the_specified_12x12_eigen_solver_against_numpy_and_against_jacobi(orc):
-    """epnp_eig12 (Householder tridiagonalisation + implicit QL: the arithmetic the HIP initialiser follows operation for
-    operation) against numpy on full-rank, rank-10 (five correspondences) and badly scaled M^T M, and EPnP poses computed
-    with it against poses computed with the cyclic Jacobi solver it replaced."""
+def test_the_specified_12x12_solver_low4_against_numpy(orc):
+    """epnp_eig12_low4 — what EPnP reads of the decomposition of M^T M, the eigenvectors of the four smallest eigenvalues, by
+    Householder tridiagonalisation + bisection + inverse iteration + back-transformation (the arithmetic the HIP initialiser follows
+    operation for operation since round 4) — against numpy.linalg.eigh: eigenvalues, residuals, orthonormality, and the invariant
+    subspace on full-rank, rank-10 (five correspondences: two-fold zero), rank-8 (four points: four-fold zero) and badly scaled inputs."""
+    rng = np.random.default_rng(1)
+    for trial in range(400):
+        rows = (10, 8)[trial % 4] if trial % 4 < 2 else 2 * int(rng.integers(6, 400))
+        m = rng.normal(size=(rows, 12)) * rng.uniform(1e-2, 1e3, 12)
+        s = m.T @ m
+        w4, v4 = orc.eig12_low4(s)
+        w_np, v_np = np.linalg.eigh(s)
+        top = w_np[-1]
+        assert np.abs(w4 - w_np[:4]).max() <= 1e-14 * top and np.all(np.diff(w4) >= 0)
+        assert np.abs(v4 @ v4.T - np.eye(4)).max() <= 2e-12
+        assert np.abs(s @ v4.T - v4.T * w4).max() <= 1e-12 * top
+        if w_np[4] - w_np[3] > 1e-6 * top:                                   # the subspace is defined: it is numpy's
+            P = v_np[:, :4]
+            assert np.abs(v4 - (v4 @ P) @ P.T).max() <= 1e-9
+        if rows == 10:
+            assert np.abs(s @ v4[:2].T).max() <= 1e-11 * top                  # the first two span the null space
+    # well-separated spectrum: the individual eigenvectors are numpy's up to sign
+    q, _ = np.linalg.qr(rng.normal(size=(12, 12)))
+    s = (q * np.geomspace(1e-6, 1.0, 12)) @ q.T
+    w4, v4 = orc.eig12_low4(s)
+    assert np.abs(np.abs(v4 @ q[:, :4]) - np.eye(4)).max() <= 1e-9 and np.abs(w4 - np.geomspace(1e-6, 1.0, 12)[:4]).max() <= 1e-15
+    # diagonal, already tridiagonal and zero inputs (reflectors with nothing to annihilate, decoupled blocks): finite, orthonormal
+    d = np.diag(rng.uniform(1, 5, 12)); d[3, 4] = d[4, 3] = 0.7
+    w4, v4 = orc.eig12_low4(d)
+    assert np.abs(w4 - np.linalg.eigvalsh(d)[:4]).max() <= 1e-14 and np.abs(d @ v4.T - v4.T * w4).max() <= 1e-13
+    w4, v4 = orc.eig12_low4(np.zeros((12, 12)))
+    assert np.all(w4 == 0) and np.isfinite(v4).all() and np.abs(v4 @ v4.T - np.eye(4)).max() <= 1e-14
+
+
+def test_the_complete_decompositions_kept_as_cross_checks(orc):
+    """epnp_eig12 (Householder tridiagonalisation + implicit QL: round 3's specification) against numpy on full-rank, rank-10
+    (five correspondences) and badly scaled M^T M, and EPnP poses computed with the specification (low4) against poses
+    computed with either complete decomposition (QL, cyclic Jacobi)."""
     rng = np.random.default_rng(1)
     for trial in range(60):
         rows = 10 if trial % 3 == 0 else 2 * int(rng.integers(6, 400))
@@ -69,17 +103,23 @@ def test_the_specified_12x12_eigen_solver_against_numpy_and_against_jacobi(orc):
     assert np.abs(w - np.linalg.eigvalsh(d)[::-1]).max() <= 1e-14 and np.abs(vt.T @ np.diag(w) @ vt - d).max() <= 1e-14
     w, vt = orc.eig12(np.zeros((12, 12)))
     assert np.all(w == 0) and np.abs(vt @ vt.T - np.eye(12)).max() == 0
-    # EPnP end to end with either eigen-solver: the same pose on well-posed data
+    # EPnP end to end with each eigen-solver: the same pose on well-posed data (noisy 300-point set; noise-free 5-point samples,
+    # whose two-dimensional null space every solver spans with a basis of its own)
     X = (rng.uniform(-1, 1, (300, 3)) * np.array([2.0, 0.8, 0.9])).astype(np.float32)
     R = _rodrigues(np.array([0.05, -0.6, 0.02])); t = np.array([1.2, 1.4, 14.0])
     x = (_project(X, R, t) + rng.normal(0, 0.3, (300, 2))).astype(np.float32)
-    r_ql, t_ql, _ = orc.epnp(X, x, K)
-    orc.set_epnp_eig_mode(True)
-    try:
-        r_j, t_j, _ = orc.epnp(X, x, K)
-    finally:
-        orc.set_epnp_eig_mode(False)
-    assert np.abs(r_ql - r_j).max() <= 1e-8 and np.abs(t_ql - t_j).max() <= 1e-7
+    x5 = _project(X[:5], R, t).astype(np.float32)
+    r_s, t_s, _ = orc.epnp(X, x, K)
+    r5_s, t5_s, _ = orc.epnp(X[:5], x5, K)
+    for mode in (1, 2):
+        orc.set_epnp_eig_mode(mode)
+        try:
+            r_m, t_m, _ = orc.epnp(X, x, K)
+            r5_m, t5_m, _ = orc.epnp(X[:5], x5, K)
+        finally:
+            orc.set_epnp_eig_mode(0)
+        assert np.abs(r_s - r_m).max() <= 1e-8 and np.abs(t_s - t_m).max() <= 1e-7
+        assert np.abs(r5_s - r5_m).max() <= 1e-5 and np.abs(t5_s - t5_m).max() <= 1e-4
 
 
 def test_cv_rng_is_the_published_multiply_with_carry_generator(orc):

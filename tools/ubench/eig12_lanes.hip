@@ -15,7 +15,7 @@ __device__ __forceinline__ double dpp_mov(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-#include "../../monorun_amd/csrc/epnp_eig_lanes.inc"
+#include "epnp_eig_lanes_round3.inc"
 
 template <int LPM, int GPW>
 static void run(const char *name, const double *dm, double *de, int nprob, std::vector<double> &ev) {

@@ -14,7 +14,7 @@ __device__ __forceinline__ double dpp_mov(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-#include "../../monorun_amd/csrc/epnp_eig_lanes.inc"
+#include "epnp_eig_lanes_round3.inc"
 int main(int argc, char **argv) {
     const int nprob = 30 * 1024, rank = argc > 1 ? atoi(argv[1]) : 10;
     std::vector<double> h((size_t)nprob * 144);
