@@ -935,19 +935,11 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             ea.h0 = round == 0 ? 0 : first; ea.h1 = round == 0 ? first : kEpMaxIters;
             const int nh = ea.h1 - ea.h0;
             if (nh <= 0) break;
-            const long long lanes = (long long)a.B * nh;
-            const int *gate = ea.w.meta + (round == 0 ? EP_M_MODE : EP_M_PENDING);
-            const int want = round == 0 ? (int)EP_MODE_RANSAC : 1;
-            hipLaunchKernelGGL(epnp_hyp_mtm_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, ea);
-            // one quad per matrix, 16 matrices per wave (fixed trip counts: nothing to gain from fewer matrices per wave)
-            hipLaunchKernelGGL((epnp_eig12_kernel<16>), dim3((unsigned)((lanes + 15) / 16)), dim3(64), 0, st, (const double *)ea.w.mtm, ea.w.ev, lanes, ea.w.nq, 1LL,
-                               gate, kEpMaxIters, want, nh, ea.h0, (const int *)(ea.w.meta + EP_M_NITERS));
-            hipLaunchKernelGGL(epnp_hyp_pose_kernel, dim3((unsigned)((lanes + 63) / 64), 3), dim3(64), 0, st, ea);
+            const long long quads = (long long)a.B * nh;
+            hipLaunchKernelGGL(epnp_hyp_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(64), 0, st, ea);
             hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
         }
-        hipLaunchKernelGGL((epnp_eig12_kernel<16>), dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, (const double *)ea.w.mtm_r, ea.w.ev_r, (long long)a.B, (long long)a.B, 1LL,
-                           (const int *)(ea.w.meta + EP_M_REFIT), 1, 1, 0, 0, (const int *)nullptr);
-        hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(kEpPoseThreads), 0, st, ea);
+        hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);
         hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
         HIP_TRY(hipGetLastError());
         return MR_OK;

@@ -1,7 +1,7 @@
 """Bitwise comparison of the GPU's 12x12 solver (dump written by tools/ubench/eig12_low4 on the GPU box) with the CPU restatement
-oracle.eig12_low4 (test infrastructure; development aid).   python tools/check_eig12_low4.py gpurun_out/eig12_low4.bin"""
+oracle.eig12_low4 (test infrastructure; development aid).   python tests/sweeps/check_eig12_low4.py gpurun_out/eig12_low4.bin"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as orc
 raw = open(sys.argv[1], 'rb').read()

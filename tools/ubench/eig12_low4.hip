@@ -1,7 +1,7 @@
 // Microbenchmark (development aid): the library's 12x12 solver since round 4 (monorun_amd/csrc/epnp_eig_low4.inc: the four smallest
 // eigenvectors by tridiagonalisation + bisection + inverse iteration, one quad per matrix) alone, on rank-10 Gram matrices like the
 // five-point M^T M.  Prints launch times for several matrices-per-wave settings and writes inputs + results to a file so that the
-// CPU restatement (oracle.eig12_low4) can be compared bit for bit (tools/check_eig12_low4.py).
+// CPU restatement (oracle.eig12_low4) can be compared bit for bit (tests/sweeps/check_eig12_low4.py).
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/eig12_low4.hip -o tools/ubench/eig12_low4 && tools/ubench/eig12_low4 [nprob] [dump-file]
 #include <hip/hip_runtime.h>
 #include <cstdio>
