@@ -428,6 +428,9 @@ def run(args):
     if use_dist and rccl is not None:
         variants['grouped_collective'] = {'steps': full, 'elapsed': Loop(L, G_SEC if G_MAIN == 1 else 1).timed(full, min(args.warmup, NB)),
                                           'steps_per_collective': G_SEC if G_MAIN == 1 else 1}
+    # steady state: the same loop over >= 240 steps (the driver's 20-step window carries ~10 % of pipeline fill and drain)
+    ss_steps = ((max(240, args.steps) + NB - 1) // NB) * NB
+    variants['steady_state'] = {'steps': ss_steps, 'elapsed': Loop(L, G_MAIN).timed(ss_steps, min(args.warmup, NB))}
     comm = None
     if use_dist and oversub:
         comm = {'backend': 'gloo (host-staged; MR_BENCH_OVERSUBSCRIBE test mode: several ranks share one GPU, which RCCL refuses)',
@@ -468,6 +471,25 @@ def run(args):
     kernel_ms = float(k_ms.mean())
     per_batch_ms = [float(k_ms[bi::NB].mean()) for bi in range(NB)]
 
+    # ... and of the timed regime's own launches: HIP events on the PIPELINE's streams (the streams these kernels are launched on)
+    # around every launch of a 240-step run of the timed loop's issue pattern.  The launches overlap, so this is the time a launch is
+    # resident, not what it costs the chip: the chip-level rate is value x bytes.
+    k_fl_ms = None
+    if L > 1 and not use_dist:
+        pp = pipe_of(L_ASKED)
+        nfl = 240
+        fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nfl)]
+        for i in range(2 * L):
+            pp.submit(launches[i % NB][i % S], slot=i % S)
+        pp.drain()
+        for i, (e0, e1) in enumerate(fev):
+            st = pp.streams[(i % S) % pp.depth]
+            e0.record(st)
+            launches[i % NB][i % S].run(pp.handles[(i % S) % pp.depth])
+            e1.record(st)
+        pp.drain()
+        k_fl_ms = np.array([e0.elapsed_time(e1) for e0, e1 in fev])
+
     if not diag_first:
         valid_frac, flops_per_launch, it_hist = diagnose()
 
@@ -479,16 +501,21 @@ def run(args):
         total = B_PER_GPU * world * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         achieved = BYTES_PER_SOLVE * B_PER_GPU / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_iso = None, None, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # HBM bytes per launch from the PMC passes (see profiles/README.md)
         if os.path.exists(tfile) and not stress:
             try:
                 tj = json.load(open(tfile))
-                traffic, traffic_src = tj.get('hbm_bytes_per_launch'), 'profiles/traffic.json (' + str(tj.get('source', 'rocprofv3 --pmc passes of this command, committed')) + '); replayed, not measured in this run'
+                traffic_iso = tj.get('hbm_bytes_per_launch')
+                traffic_fl = (tj.get('in_flight_kernel') or {}).get('hbm_bytes_per_launch')
+                traffic = traffic_fl if (L > 1 and traffic_fl) else traffic_iso
+                traffic_src = ('profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_round.sh ' + str(tj.get('tag', '')) + ', committed: ' +
+                               ('the 2-waves-per-object kernel the timed region launches, counted on isolated launches of it' if (L > 1 and traffic_fl) else 'the isolated-launch kernel') +
+                               '); replayed, not measured in this run')
             except Exception:  # noqa: BLE001
                 traffic = None
         valu = None
-        for sname in ('r03_summary.json', 'r02_summary.json', 'r01_summary.json'):           # PMC instruction counts of the same command
+        for sname in ('r04_summary.json', 'r03_summary.json', 'r02_summary.json', 'r01_summary.json'):           # PMC instruction counts of the same command
             sfile = os.path.join(ROOT, 'profiles', sname)
             if os.path.exists(sfile) and not stress:
                 try:
@@ -522,23 +549,28 @@ def run(args):
                                  'every step is one full 1024-object launch into its own buffers, all outputs complete inside the timed window '
                                  'and verified bit-identical to isolated launches after it') if L > 1 else 'one stream: every launch waits for the previous one',
                        'parallelism': f'objects sharded x{world}' + (f', 1 all-gather of 88 B/object x {comm["steps_per_collective"]} step(s) per collective' if (world > 1 and comm) else '')},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'pnp_uncert_kernel', 'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
-                         'measured_on': ('HIP events around ISOLATED launches on one stream (the library\'s own choice there: 4 waves per object), rotating over the '
-                                         'batches, in this run; rocprofv3 of `bench.py --in-flight 1` agrees (profiles/rNN_kernel_stats.csv).  With launches in flight the '
-                                         'timed region runs the 2-waves-per-object instantiation of the same kernel, several launches overlapping: a per-launch '
-                                         'duration there (~100 us each, profiles/rNN_kernel_stats_in_flight.csv) measures the overlap, not the kernel — the chip-level '
-                                         'rate of the timed region is `in_flight`') if L > 1 else 'HIP events around the launches of the timed loop\'s kernel on its stream',
-                         'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)),
-                         'kernel_ms_per_batch': per_batch_ms,
-                         'batch0_only': {'kernel_ms': per_batch_ms[0], 'frac': BYTES_PER_SOLVE * B_PER_GPU / (per_batch_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         'note': 'batch 0 (the config seed) alone — what round 1 measured (67.6 us, 0.043) before the steps rotated over '
-                                                 'distinct batches; a launch lasts as long as its slowest object, so batches differ'},
-                         'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU, 'valu_issue': valu,
+            'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         # filled in below: `achieved` / `frac` describe the TIMED REGIME (the kernel instantiation and issue pattern `value` was measured on)
+                         'achieved': None, 'frac': None,
+                         'kernel': f'pnp_uncert_kernel<float, {((fl_main >> 8) & 15) or 4}, false>' if not stress else f'pnp_uncert_kernel<__half, {((fl_main >> 8) & 15) or "auto"}, false>',
+                         'launches_in_flight': L,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU,
+                         'isolated_launch': {
+                             'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'kernel': f'pnp_uncert_kernel<float, {((fl_one >> 8) & 15) or 4}, false>' if not stress else 'pnp_uncert_kernel<__half, auto, false>',
+                             'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
+                             'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)), 'kernel_ms_per_batch': per_batch_ms,
+                             'measured_on': 'HIP events around ISOLATED launches on one stream (the library\'s own choice there: 4 waves per object), rotating over the '
+                                            'batches, in this run; rocprofv3 of `bench.py --in-flight 1` agrees (profiles/rNN_kernel_stats.csv).  NOT the instantiation the '
+                                            'timed region launches when launches_in_flight > 1',
+                             'batch0_only': {'kernel_ms': per_batch_ms[0], 'frac': BYTES_PER_SOLVE * B_PER_GPU / (per_batch_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             'note': 'batch 0 (the config seed) alone; a launch lasts as long as its slowest object, so batches differ'},
+                             'traffic': traffic_iso, 'valu_issue': valu},
                          'flops': {'fp64_flop_per_launch': flops_per_launch, 'achieved_tflops': flops_ach, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
                                    'frac_of_fp64_vector_peak': flops_ach / FP64_VECTOR_PEAK_TFLOPS,
                                    'model': f'{FLOP_PER_POINT_EVAL} FLOP x inlier points x (LM iterations + 2) per object (SURVEY 8d; iterations and inlier '
-                                            'counts read back from the kernel in this run); K0 and the mask are not counted',
+                                            'counts read back from the kernel in this run); K0 and the mask are not counted; rate per ISOLATED launch',
                                    'lm_iteration_histogram': {str(k): it_hist[k] for k in sorted(it_hist)}},
                          'note': 'formally HBM-bound (read-once streaming); in practice VALU/latency-bound: the tile is LDS-resident '
                                  'across all LM iterations (DESIGN.md)'},
@@ -558,6 +590,29 @@ def run(args):
         if 'grouped_collective' in variants:
             extra['grouped_collective'] = dict(per_s(variants['grouped_collective']), steps_per_collective=variants['grouped_collective']['steps_per_collective'],
                                                what='the same loop with the other exchange granularity (one all-gather per this many steps)')
+        chip = line['value'] / world * BYTES_PER_SOLVE / 1e9          # per GPU: algorithmic bytes of all launches / wall time of the timed region
+        line['roofline']['achieved'], line['roofline']['frac'] = chip, chip / HBM_PEAK_GBS
+        line['roofline']['measured_on'] = (
+            f'the timed region itself: algorithmic bytes of its {args.steps} launches / its wall time, per GPU ({L} launches in flight on '
+            f'{L} HIP streams, {((fl_main >> 8) & 15) or 4} waves per object) — launches overlap, so the chip-level rate is what a roofline fraction '
+            'can mean here; per-launch figures of an isolated launch are under `isolated_launch`') if L > 1 else \
+            'one launch at a time: algorithmic bytes / wall time of the timed region (per-launch HIP-event figures under `isolated_launch`)'
+        if k_fl_ms is not None:
+            line['roofline']['launch_resident_ms_in_flight'] = {
+                'avg': float(k_fl_ms.mean()), 'median': float(np.median(k_fl_ms)), 'min': float(k_fl_ms.min()), 'launches': int(len(k_fl_ms)),
+                'what': 'HIP events on the pipeline\'s own streams around every launch of a 240-step run of the timed issue pattern: how long a launch is '
+                        f'resident while {L} overlap (avg / {L} = chip time per launch); agrees with profiles/rNN_kernel_stats_in_flight.csv'}
+        ss = per_s(variants['steady_state'])
+        line['steady_state'] = dict(ss, frac=ss['value'] / world * BYTES_PER_SOLVE / 1e9 / HBM_PEAK_GBS,
+                                    what=f'the timed loop over {ss["steps"]} steps (whole rotations): the {args.steps}-step window of `value` carries the fill and drain of the {L}-deep pipeline')
+        if isinstance(extra.get('epnp_initialiser'), dict) and 'value' in extra['epnp_initialiser']:
+            ep = extra['epnp_initialiser']
+            line['reference_flow'] = {
+                'what': "the reference's own flow on the GPU — cv2.solvePnPRansac(EPNP, 30 iterations) restated, then the LM + covariance: PnPUncert(initialiser='epnp'); "
+                        "`value` above is the one-launch K0 path, which is NOT the reference's initialiser (INTEGRATION.md section 2)",
+                'value': ep['value'], 'unit': 'solves/s', 'ms_per_step': ep['ms_per_step'], 'issue': ep.get('issue'),
+                'synchronous_call': ep.get('synchronous_call'), 'in_flight': ep.get('in_flight'), 'roofline': ep.get('roofline'),
+                'launch_split_batch0_ms': {'initialiser': ep.get('epnp_ransac_launches_ms_batch0'), 'lm': ep.get('lm_launch_ms_batch0')}}
         line['roofline']['in_flight'] = {
             'launches_in_flight': L, 'achieved': line['value'] / world * BYTES_PER_SOLVE / 1e9, 'unit': 'GB/s',
             'frac': line['value'] / world * BYTES_PER_SOLVE / 1e9 / HBM_PEAK_GBS,
@@ -573,6 +628,9 @@ def run(args):
             line['speedup_vs_cpu_all_cores'] = line['value'] / cb['cpu_baseline_all_cores']['value']
             if 'cpu_baseline_epnp' in cb:
                 line['speedup_vs_cpu_epnp_1thread'] = line['value'] / cb['cpu_baseline_epnp']['value']
+            if 'cpu_baseline_epnp' in cb and 'reference_flow' in line:
+                line['reference_flow']['cpu_baseline_epnp'] = cb['cpu_baseline_epnp']
+                line['reference_flow']['speedup_vs_cpu_epnp_1thread'] = line['reference_flow']['value'] / cb['cpu_baseline_epnp']['value']
             if 'cpu_baseline_epnp' in cb and 'value' in extra.get('epnp_initialiser', {}):
                 line['speedup_epnp_initialiser_vs_cpu_epnp_1thread'] = extra['epnp_initialiser']['value'] / cb['cpu_baseline_epnp']['value']
             if 'init_given' in extra:
@@ -662,57 +720,95 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
             'what': 'host wall per call incl. output allocation and argument marshalling, 1024 objects, after the 4-DoF solve of batch 0'}
     except Exception as e:                                          # noqa: BLE001 — secondary figure
         extra['second_launches'] = {'error': repr(e)}
-    # (g) the reference's own initialiser on the GPU (PnPUncert(initialiser='epnp')): EPnP/RANSAC launch + LM launch, next to cpu_baseline_epnp
+    # (g) the reference's own flow on the GPU (PnPUncert(initialiser='epnp')): EPnP / RANSAC initialiser launches + LM launch, next to
+    #     cpu_baseline_epnp.  `value`: prepared launches (PnPEpnpLaunch: outputs, hand-over buffers and workspace allocated once) issued
+    #     back to back on ONE stream, rotating over the batches — at most one call executes at any time, the host only enqueues;
+    #     `synchronous_call`: the eager op with a host synchronisation after every call (what round 3 reported as `value`);
+    #     `in_flight`: the same prepared launches on PnPPipeline's streams.
     try:
         from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
-
-        def ep_step():
-            ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
-            return pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, ini, im, iv, z_min=0.5, inlier_opt_only=True)
-        for _ in range(2):
-            out = ep_step()
-        torch.cuda.synchronize()
-        ne = max(4, args.steps // 10)
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        t_init = t_lm = 0.0
-        t1 = time.perf_counter()
-        for _ in range(ne):
-            evs[0].record()
-            ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
-            evs[1].record()
-            out = pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, ini, im, iv, z_min=0.5, inlier_opt_only=True)
-            evs[2].record()
-            torch.cuda.synchronize()
-            t_init += evs[0].elapsed_time(evs[1]); t_lm += evs[1].elapsed_time(evs[2])
-        el = time.perf_counter() - t1
-        extra['epnp_initialiser'] = {'value': B_PER_GPU * ne / el, 'unit': 'solves/s', 'ms_per_step': el / ne * 1e3,
-                                     'epnp_ransac_launch_ms': t_init / ne, 'lm_launch_ms': t_lm / ne, 'valid': int(out[0].sum().item()),
-                                     'what': "pnp_uncert(..., initialiser='epnp') on batch 0: the reference's initialiser (30 EPnP hypotheses on cv::RNG subsets, "
-                                             'consensus, adaptive iteration count, EPnP re-fit) as its own sequence of launches, then the LM + covariance launch; '
-                                             'masks and poses equal the CPU restatement (tests/test_gpu_epnp.py); the CPU counterpart is cpu_baseline_epnp'}
-        # the same flow with prepared launches in flight (PnPPipeline): the stages are latency chains, several batches overlap
         from monorun_amd import PnPEpnpLaunch, PnPPipeline
+        mk_ep = lambda bi, fl=0: PnPEpnpLaunch(*dev_batches[bi % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[bi % NB][6],
+                                               inlier_opt_only=True, flags=fl)
+        nrot = min(NB, 4)
+        le1 = [mk_ep(i) for i in range(nrot)]
+        for l in le1:
+            l.run()
+        torch.cuda.synchronize()
+        ne = max(24, args.steps)
+        ne -= ne % nrot
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t1 = time.perf_counter()
+        for i in range(ne):
+            le1[i % nrot].run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        # the split of one call: HIP events on the launch stream around the initialiser's launches and the LM launch, batch 0
+        t_init = t_lm = 0.0
+        for _ in range(6):
+            evs[0].record(); le1[0].lib.mr_epnp_ransac_batched(*le1[0].args_init, torch.cuda.current_stream().cuda_stream)
+            evs[1].record(); le1[0].lib.mr_pnp_uncert_from_init_batched(*le1[0].args_lm, torch.cuda.current_stream().cuda_stream)
+            evs[2].record(); torch.cuda.synchronize()
+            t_init += evs[0].elapsed_time(evs[1]) / 6; t_lm += evs[1].elapsed_time(evs[2]) / 6
+        ref = pnp_uncert_from_init_device(*dev_batches[0][:6], *epnp_ransac_device(*dev_batches[0][:4], epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[0][6])[:3],
+                                          z_min=0.5, inlier_opt_only=True)
+        torch.cuda.synchronize()
+        same1 = bool(torch.equal(le1[0].pose, ref[1]) and torch.equal(le1[0].mask, ref[4]) and torch.equal(le1[0].valid, ref[0]))
+        ep = {'value': B_PER_GPU * ne / el, 'unit': 'solves/s', 'ms_per_step': el / ne * 1e3, 'steps': ne, 'distinct_batches': nrot,
+              'epnp_ransac_launches_ms_batch0': t_init, 'lm_launch_ms_batch0': t_lm, 'valid': int(ref[0].sum().item()),
+              'outputs_equal_the_eager_op': same1,
+              'issue': 'prepared launches (PnPEpnpLaunch) back to back on ONE stream, no host synchronisation between calls: one call at a time on the device',
+              'what': "pnp_uncert(..., initialiser='epnp'): the reference's initialiser (30 EPnP hypotheses on cv::RNG subsets, consensus, adaptive "
+                      'iteration count, EPnP re-fit) as seven launches, then the LM + covariance launch; masks and poses equal the CPU '
+                      'restatement (tests/test_gpu_epnp.py); the CPU counterpart is cpu_baseline_epnp'}
+        # the eager op, one host synchronisation per call (allocations + argument marshalling + the synchronisation inside the figure)
+        ns = max(8, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(ns):
+            ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
+            out = pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, ini, im, iv, z_min=0.5, inlier_opt_only=True)
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        ep['synchronous_call'] = {'value': B_PER_GPU * ns / el, 'unit': 'solves/s', 'ms_per_step': el / ns * 1e3, 'steps': ns,
+                                  'what': 'the eager op on batch 0 with torch.cuda.synchronize() after every call (round 3 reported this as `value`)'}
+        extra['epnp_initialiser'] = ep
+        # the same flow with prepared launches in flight (PnPPipeline): the stages are latency chains, several batches overlap
         pipe = PnPPipeline(dev, depth=4, record_events=False)
         nl = max(pipe.depth, 1)
-        le = [PnPEpnpLaunch(*dev_batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[i % NB][6], inlier_opt_only=True,
-                            flags=pipe.flags_for(B_PER_GPU, P)) for i in range(nl)]       # the LM launch with the waves per object the pipeline asks for
+        le = [mk_ep(i, pipe.flags_for(B_PER_GPU, P)) for i in range(nl)]       # the LM launch with the waves per object the pipeline asks for
         for i in range(2 * nl):
             pipe.submit(le[i % nl], slot=i % nl)
         pipe.drain()
-        nf = max(8, args.steps // 2)
+        nf = max(40, 2 * args.steps)
         t1 = time.perf_counter()
         for i in range(nf):
             pipe.submit(le[i % nl], slot=i % nl)
         pipe.drain()
         el = time.perf_counter() - t1
-        ref = pnp_uncert_from_init_device(*dev_batches[0][:6], *epnp_ransac_device(*dev_batches[0][:4], epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[0][6])[:3],
-                                          z_min=0.5, inlier_opt_only=True)
-        torch.cuda.synchronize()
         same = bool(torch.equal(le[0].pose, ref[1]) and torch.equal(le[0].mask, ref[4]) and torch.equal(le[0].valid, ref[0]))
-        extra['epnp_initialiser']['in_flight'] = {'value': B_PER_GPU * nf / el, 'unit': 'solves/s', 'ms_per_step': el / nf * 1e3, 'launches_in_flight': nl, 'steps': nf,
-                                                  'distinct_batches': min(nl, NB), 'outputs_equal_the_one_at_a_time_results': same,
-                                                  'what': 'PnPEpnpLaunch objects (initialiser + LM, own workspace and outputs) submitted round-robin to PnPPipeline'}
-        del le
+        ep['in_flight'] = {'value': B_PER_GPU * nf / el, 'unit': 'solves/s', 'ms_per_step': el / nf * 1e3, 'launches_in_flight': nl, 'steps': nf,
+                           'distinct_batches': min(nl, NB), 'outputs_equal_the_one_at_a_time_results': same,
+                           'what': 'PnPEpnpLaunch objects (initialiser + LM, own workspace and outputs) submitted round-robin to PnPPipeline'}
+        # roofline of the flow: the algorithmic bytes are config 2's (every correspondence read once, the outputs written once); the
+        # launches re-read the tile (front, consensus, re-fit, LM: 4 x) and hand over through a 17 MB workspace — HBM traffic from the
+        # PMC passes is replayed from profiles/ when present
+        alg = BYTES_PER_SOLVE * B_PER_GPU
+        rf = {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'algorithmic_bytes_per_call': alg,
+              'achieved': alg / (ep['ms_per_step'] * 1e-3) / 1e9, 'frac': alg / (ep['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              'in_flight': {'achieved': alg / (ep['in_flight']['ms_per_step'] * 1e-3) / 1e9, 'frac': alg / (ep['in_flight']['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+              'traffic': None,
+              'note': 'latency-bound: each of the eight launches is a serial chain per object (Jacobi SVDs, Gauss-Newton, bisection) that leaves most issue slots idle; '
+                      'the per-launch table is profiles/r04_epnp_launches.txt'}
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_epnp_traffic.json')
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                rf['traffic'] = tj.get('hbm_bytes_per_call')
+                rf['traffic_source'] = 'profiles/r04_epnp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_epnp_path.py, committed); replayed, not measured in this run'
+            except Exception:  # noqa: BLE001
+                pass
+        ep['roofline'] = rf
+        del le, le1
     except Exception as e:                                          # noqa: BLE001 — secondary figure
         extra['epnp_initialiser'] = {'error': repr(e)}
     # (f) the NOC path at B = 1024: raw head output -> pose, fused (one launch) and as two launches (K2 decode, then the PnP kernel)

@@ -70,6 +70,9 @@ extern "C" {
                                           is consulted (1..30; 0 = the default, 8); the rest are solved only for the objects whose loop still
                                           wants iterations.  Changes the work done, never the result */
 #define MR_EPNP_FIRST_ROUND_MASK  (0x1F << MR_EPNP_FIRST_ROUND_SHIFT)
+#define MR_EPNP_REFIT_F32   0x40      /* mr_epnp_ransac_batched: normalise the image points of solvePnPRansac's final re-fit in float32 (round 3's
+                                         reading of OpenCV) instead of float64 (the published solvePnPRansac converts the inliers to CV_64F first;
+                                         the default since round 4) — oracle/epnp.inc "version-dependent decisions" (i) */
 
 /* diag[] layout (per object, 4 floats): */
 #define MR_DIAG_LM_ITERATIONS 0       /* LM loop passes executed                                  */

@@ -18,6 +18,7 @@ SO = os.environ.get('MR_PNP_SO') or os.path.join(_HERE, 'libmonorun_pnp.so')    
 MR_F32, MR_F16, MR_F64, MR_BF16 = 0, 1, 2, 3
 MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
 MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES, MR_ANY_ORDER = 0x4, 0x8, 0x10, 0x20
+MR_EPNP_REFIT_F32 = 0x40
 MR_WAVES_SHIFT = 8
 MR_LM_MAXIT_SHIFT = 16
 MR_EPNP_FIRST_ROUND_SHIFT = 24

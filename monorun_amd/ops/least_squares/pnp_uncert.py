@@ -206,7 +206,7 @@ class PnPEpnpLaunch:
     """A prepared launch of the REFERENCE's flow over device-resident inputs: its initialiser (``mr_epnp_ransac_batched``: the
     launches of csrc/epnp_stages.inc, pnp_uncert_cpu.py:33-68) followed by the LM + covariance launch
     (``mr_pnp_uncert_from_init_batched``) on the same stream.  Outputs, the initialiser's hand-over buffers and its workspace
-    (``mr_epnp_workspace_bytes``: 65 MB per 1024 objects) are allocated once; ``run()`` only enqueues.  The stages are latency
+    (``mr_epnp_workspace_bytes``: 17 MB per 1024 objects) are allocated once; ``run()`` only enqueues.  The stages are latency
     chains that leave most issue slots of the chip idle, so several of these launches in flight (``PnPPipeline.submit``)
     overlap almost for free."""
 
@@ -238,7 +238,7 @@ class PnPEpnpLaunch:
         self.diag = torch.empty(B, 4, **f32) if with_diag else None
         self.B = B
         head = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[x2d.dtype], cam.data_ptr(), cam.shape[0]]
-        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), (int(flags) & 0x7) | ((max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT) if first_round is not None else 0),
+        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), (int(flags) & 0x47) | ((max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT) if first_round is not None else 0),
                                  int(max_iters), self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
                                  self.init_diag.data_ptr() if self.init_diag is not None else None, None, self.work.data_ptr(), self.work.numel()]
         self.args_lm = head + [ur.data_ptr(), vr.data_ptr(), ur.shape[0], self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
@@ -475,6 +475,9 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
         else:
             raise ValueError(f"initialiser must be 'k0' or 'epnp', got {initialiser!r}")
         odt = coords_2d.dtype
+        if use_6dof and cov_symeig_rule:
+            raise ValueError('cov_symeig_rule tests the 4x4 covariance of [yaw, t] (pnp_uncert.py:77-85); it has no meaning for the 6x6 '
+                             'covariance that use_6dof=True returns')
         if use_6dof:
             valid6, pose6, cov6, _ = pnp6_refine_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, mask, pose, valid, z_min=z_min)
             return ((valid & valid6).to(device=src_dev, dtype=torch.bool), pose6[:, :3].to(device=src_dev, dtype=odt),
@@ -496,15 +499,19 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
 class PnPUncert(torch.nn.Module):
 
     def __init__(self, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, coord_istd_normalize=False,
-                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser='k0', epnp_first_round=None):
+                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser='k0', epnp_first_round=None, cov_symeig_rule=False):
         """Module form (constructor keywords of the reference, pnp_uncert.py:93-99; no parameters, no buffers).
         epnp_istd_thres: a point is an istd inlier when both of its istd components reach this factor times the object's
         mean; inlier_opt_only: the LM refines on the inlier set only; coord_istd_normalize: divide the istd map by its
-        per-object mean (clamped at eps) first.  initialiser ('k0' | 'epnp', not a reference keyword): see ``pnp_uncert``."""
+        per-object mean (clamped at eps) first.  initialiser ('k0' | 'epnp'), epnp_first_round, cov_symeig_rule (not reference
+        keywords): see ``pnp_uncert``.  THE DEFAULT INITIALISER IS NOT THE REFERENCE'S: the reference's own config dict builds the
+        one-launch K0 path; ``initialiser='epnp'`` selects the reference's flow."""
         super().__init__()
         if initialiser not in ('k0', 'epnp'):
             raise ValueError(f"initialiser must be 'k0' or 'epnp', got {initialiser!r}")
-        self.initialiser, self.epnp_first_round = initialiser, epnp_first_round
+        if cov_symeig_rule and use_6dof:
+            raise ValueError('cov_symeig_rule applies to the 4-DoF covariance only (use_6dof=True returns a 6x6 one)')
+        self.initialiser, self.epnp_first_round, self.cov_symeig_rule = initialiser, epnp_first_round, cov_symeig_rule
         self.z_min, self.epnp_istd_thres, self.inlier_opt_only = z_min, epnp_istd_thres, inlier_opt_only
         self.coord_istd_normalize, self.eps = coord_istd_normalize, eps
         self.forward_exact_hessian, self.use_6dof = forward_exact_hessian, use_6dof
@@ -516,4 +523,5 @@ class PnPUncert(torch.nn.Module):
         return pnp_uncert(coords_2d, istd, coords_3d, cam_mats, u_range, v_range, z_min=self.z_min,
                           epnp_istd_thres=self.epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres,
                           inlier_opt_only=self.inlier_opt_only, forward_exact_hessian=self.forward_exact_hessian,
-                          use_6dof=self.use_6dof, initialiser=self.initialiser, epnp_first_round=self.epnp_first_round)
+                          use_6dof=self.use_6dof, initialiser=self.initialiser, epnp_first_round=self.epnp_first_round,
+                          cov_symeig_rule=self.cov_symeig_rule)

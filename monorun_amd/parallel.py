@@ -23,36 +23,44 @@ def shard_bounds(n, rank, world):
 
 class PackedResults:
     """One flat uint8 buffer holding the per-object outputs of a shard; typed views alias it, so the
-    kernel writes straight into the buffer that the collective sends (no packing kernels)."""
+    kernel writes straight into the buffer that the collective sends (no packing kernels).
+    extra_f32: additional float32 columns per object riding in the same row (e.g. the decoded dimensions a consumer on another rank
+    needs next to the pose: tools/kitti_val.py) — view ``extra`` (n, extra_f32); row = 88 + 4 extra_f32 bytes."""
 
-    def __init__(self, n, device, buf=None):
-        """buf: an existing uint8 tensor of max(n,1)*ROW_BYTES bytes to alias (e.g. one slot of a larger buffer that is exchanged
+    def __init__(self, n, device, buf=None, extra_f32=0):
+        """buf: an existing uint8 tensor of max(n,1)*row_bytes bytes to alias (e.g. one slot of a larger buffer that is exchanged
         as a whole: several steps' results in ONE collective), or None to allocate."""
         self.n = n
+        self.extra_f32 = int(extra_f32)
+        self.row_bytes = ROW_BYTES + 4 * self.extra_f32
         if buf is None:
-            buf = torch.zeros(max(n, 1) * ROW_BYTES, dtype=torch.uint8, device=device)
-        assert buf.dtype == torch.uint8 and buf.is_contiguous() and buf.numel() == max(n, 1) * ROW_BYTES and buf.data_ptr() % 4 == 0
+            buf = torch.zeros(max(n, 1) * self.row_bytes, dtype=torch.uint8, device=device)
+        assert buf.dtype == torch.uint8 and buf.is_contiguous() and buf.numel() == max(n, 1) * self.row_bytes and buf.data_ptr() % 4 == 0
         self.buf = buf
         o = 0
         self.pose = self.buf[o:o + n * 16].view(torch.float32).view(n, 4); o += n * 16
         self.cov = self.buf[o:o + n * 64].view(torch.float32).view(n, 4, 4); o += n * 64
         self.tr = self.buf[o:o + n * 4].view(torch.float32); o += n * 4
+        self.extra = None
+        if self.extra_f32:
+            self.extra = self.buf[o:o + n * 4 * self.extra_f32].view(torch.float32).view(n, self.extra_f32); o += n * 4 * self.extra_f32
         self.valid = self.buf[o:o + n]
 
     @staticmethod
-    def unpack(flat, n):
-        """flat: (world, per*ROW_BYTES) uint8 -> dict of (world*per, ...) tensors, truncated by the caller."""
+    def unpack(flat, n, extra_f32=0):
+        """flat: (world, per*row_bytes) uint8 -> dict of (world*per, ...) tensors, truncated to the n real objects."""
         w = flat.shape[0]
-        per = flat.shape[1] // ROW_BYTES
+        per = flat.shape[1] // (ROW_BYTES + 4 * int(extra_f32))
         o = 0
         pose = flat[:, o:o + per * 16].contiguous().view(torch.float32).view(w * per, 4); o += per * 16
         cov = flat[:, o:o + per * 64].contiguous().view(torch.float32).view(w * per, 4, 4); o += per * 64
         tr = flat[:, o:o + per * 4].contiguous().view(torch.float32).view(w * per); o += per * 4
-        valid = flat[:, o:o + per].contiguous().view(w * per)
+        out = dict(pose=pose, cov=cov, tr=tr)
+        if extra_f32:
+            out['extra'] = flat[:, o:o + per * 4 * extra_f32].contiguous().view(torch.float32).view(w * per, extra_f32); o += per * 4 * extra_f32
+        out['valid'] = flat[:, o:o + per].contiguous().view(w * per).bool()
         # shards are padded to `per`; the global order is rank-major, object n' = rank*per + i
-        keep = torch.arange(w * per, device=flat.device) < n if n < w * per else None
-        out = dict(pose=pose, cov=cov, tr=tr, valid=valid.bool())
-        if keep is not None:
+        if n < w * per:
             out = {k: v[:n] for k, v in out.items()}
         return out
 
@@ -60,22 +68,30 @@ class PackedResults:
 def all_gather_results(packed, per, group=None):
     """All-gather the packed shard buffers.  Returns (world, per*ROW_BYTES) uint8 on every rank."""
     world = dist.get_world_size(group)
-    assert packed.buf.numel() == max(per, 1) * ROW_BYTES or packed.n == per
+    assert packed.buf.numel() == max(per, 1) * packed.row_bytes or packed.n == per
     out = torch.empty(world * packed.buf.numel(), dtype=torch.uint8, device=packed.buf.device)
     dist.all_gather_into_tensor(out, packed.buf, group=group)
     return out.view(world, -1)
 
 
-def sharded_pnp(solve_shard, n_objects, device, group=None):
+def sharded_pnp(solve_shard, n_objects, device, group=None, extra_f32=0, exchange=None):
     """Run `solve_shard(lo, hi, packed)` on this rank's contiguous shard (it must fill `packed`'s views
-    for hi-lo objects) and exchange the results.  Returns the unpacked global results on every rank."""
+    for hi-lo objects) and exchange the results in ONE all-gather.  Returns the unpacked global results on every rank.
+    exchange: None = torch.distributed's all_gather_into_tensor (RCCL under the 'nccl' backend, gloo on CPU), or a
+    ``RcclAllGather`` (private communicator on a side stream; the current stream then waits for its completion event)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi, per = shard_bounds(n_objects, rank, world)
-    packed = PackedResults(per, device)
+    packed = PackedResults(per, device, extra_f32=extra_f32)
     if hi > lo:
         solve_shard(lo, hi, packed)
-    flat = all_gather_results(packed, per, group)
-    return PackedResults.unpack(flat, n_objects)
+    if exchange is None:
+        flat = all_gather_results(packed, per, group)
+    else:
+        recv = torch.empty(world * packed.buf.numel(), dtype=torch.uint8, device=packed.buf.device)
+        torch.cuda.current_stream(packed.buf.device).wait_event(exchange.gather(packed.buf, recv))
+        exchange.forget(packed.buf)
+        flat = recv.view(world, -1)
+    return PackedResults.unpack(flat, n_objects, extra_f32=extra_f32)
 
 
 # ---------------------------------------------------------------------------------------------------

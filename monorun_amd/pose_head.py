@@ -419,10 +419,16 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
                    apply_cov_correction=True, fused=True, **decode_kw):
     """NOC-head output -> pose results dict (what monorun_roi_head.py:509-534 produces).
     fused=True: ONE launch (decode inside the PnP kernel); fused=False: K2 then the PnP kernel (two launches,
-    the decoded maps are materialised) — both give bit-identical results."""
+    the decoded maps are materialised) — both give bit-identical results.  The one-launch kernel runs this repository's initialiser
+    K0; a head whose ``pnp`` was built with ``initialiser='epnp'`` (the reference's flow, uncert_prop_pnp_optimizer.py:86-95 ->
+    pnp_uncert_cpu.py:33-68), ``forward_exact_hessian``, ``coord_istd_normalize`` or ``cov_symeig_rule`` takes the K2 + module path
+    whatever ``fused`` says."""
     p = pose_head.pnp
-    if fused and (getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False)):
-        fused = False               # options the one-launch kernel does not implement: take the module path, which honours them
+    if fused and (getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False) or getattr(p, 'cov_symeig_rule', False)
+                  or getattr(p, 'initialiser', 'k0') != 'k0'):
+        # options the one-launch kernel does not implement — among them the reference's own initialiser (initialiser='epnp': its
+        # launches read the decoded maps) — take the module path, which honours them: K2, then PnPUncert.forward
+        fused = False
     if fused:
         sd = decode_kw.get('ref_length', 1.6) * decode_kw.get('ref_focal_y', 722) * decode_kw.get('target_std', 0.15)
         ret_val, yaw, t_vec, cov, inlier_mask, dims, dims_var, cov_calib = pnp_from_head(
@@ -446,7 +452,8 @@ def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_in
 
 
 class PoseFromHeadLaunch:
-    """The per-image regime (monorun_roi_head.py:452: one image per forward, <= ~100 proposals): a PREPARED fused launch.
+    """The per-image regime (monorun_roi_head.py:452: one image per forward, <= ~100 proposals): a PREPARED fused launch — or, for
+    a head built with ``pnp.initialiser='epnp'`` (the reference's flow), the prepared sequence K2 -> EPnP / RANSAC -> LM.
 
     ``pose_from_head`` marshals ~60 ctypes arguments and allocates its outputs on every call (~40 us of host time, more than
     the kernel itself takes at B = 100).  Here every argument is built once over static input / output tensors;
@@ -479,9 +486,36 @@ class PoseFromHeadLaunch:
         mu, sd, nm, ns = _const(dim_means, dev), _const(dim_stds, dev), _const(noc_means, dev), _const(noc_stds, dev)
         P = h * w
         p = pose_head.pnp
-        if getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False):
-            raise ValueError('PoseFromHeadLaunch prepares the one-launch kernel: forward_exact_hessian / coord_istd_normalize '
+        if getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False) or getattr(p, 'cov_symeig_rule', False):
+            raise ValueError('PoseFromHeadLaunch prepares fixed launches: forward_exact_hessian / coord_istd_normalize / cov_symeig_rule '
                              'need pose_from_head (module path)')
+        self._epnp = None
+        if getattr(p, 'initialiser', 'k0') == 'epnp':
+            # the reference's initialiser: its launches read the decoded maps, so the prepared form is K2 (prepared) -> the initialiser's
+            # launches + the LM launch (PnPEpnpLaunch) -> calibration / distance correction as three in-place tensor operations
+            from .ops.least_squares.pnp_uncert import PnPEpnpLaunch
+            k2 = NocDecodeLaunch(self.inputs['all_pred'], self.inputs['labels'], self.inputs['flip'], self.inputs['dim'], self.inputs['dim_var'], self.inputs['rois'],
+                                 num_classes=num_classes, class_agnostic=class_agnostic, dim_means=dim_means, dim_stds=dim_stds, noc_means=noc_means,
+                                 noc_stds=noc_stds, ref_length=ref_length, ref_focal_y=ref_focal_y, target_std=target_std,
+                                 epistemic_std_gain=epistemic_std_gain, std_scale=pose_head.std_scale,
+                                 epnp_ransac_thres_ratio=pose_head.epnp_ransac_thres_ratio, coord_2d=coord_2d)
+            self.inputs['flip'] = k2.inputs['flip']                     # the one input K2 holds a private copy of: refresh THIS tensor
+            self.inputs['coord_2d'] = k2.inputs['coord_2d']
+            d = k2.out
+            ep = PnPEpnpLaunch(_planar_view(d['coords_2d']), _planar_view(d['coords_2d_istd']), _planar_view(d['coords_3d']), self.inputs['cam_intrinsic'],
+                               ur, vr, z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, epnp_ransac_thres=d['ransac_thr'],
+                               inlier_opt_only=p.inlier_opt_only, flags=flags, first_round=getattr(p, 'epnp_first_round', None))
+            s_ = torch.exp(pose_head.cov_calib_logscale.detach().to(**f32))
+            self._epnp = dict(k2=k2, ep=ep, scale=(s_ * s_[:, None]).contiguous(), sd=float(ref_length * ref_focal_y * target_std) if apply_cov_correction else 0.0)
+            self.out = dict(ret_val_u8=ep.valid, pose=ep.pose, pose_cov_pred=ep.cov, tr_radius=ep.tr, inlier_mask_u8=ep.mask,
+                            dimensions_pred=d['dims'], dimensions_var=d['dims_var'], pose_cov_calib=torch.empty(B, 4, 4, **f32))
+            o = self.out
+            o['ret_val'], o['inlier_mask'] = o['ret_val_u8'].view(torch.bool), o['inlier_mask_u8'].view(torch.bool)
+            o['yaw_pred'], o['t_vec_pred'] = o['pose'][:, :1], o['pose'][:, 1:]
+            self._keep = (ur, vr)
+            self.B = B
+            self.graph = None
+            return
         self.out = dict(ret_val_u8=torch.empty(B, device=dev, dtype=torch.uint8), pose=torch.empty(B, 4, **f32), pose_cov_pred=torch.empty(B, 4, 4, **f32),
                         tr_radius=torch.empty(B, **f32), inlier_mask_u8=torch.empty(B, P, device=dev, dtype=torch.uint8),
                         dimensions_pred=torch.empty(B, 3, **f32), dimensions_var=torch.empty(B, 3, **f32) if dim_var is not None else None,
@@ -513,7 +547,18 @@ class PoseFromHeadLaunch:
     def run(self, stream=None):
         """Enqueue the launch on `stream` (a raw hipStream_t of THIS launch's device) or on that device's current stream.  The
         library launches on the current HIP device, so the device is made current for the call."""
-        if self.B:
+        if self.B and self._epnp is not None:
+            e = self._epnp
+            with torch.cuda.device(self.dev):
+                ts = torch.cuda.ExternalStream(stream, device=self.dev) if stream is not None else torch.cuda.current_stream(self.dev)
+                e['k2'].run(ts.cuda_stream)
+                e['ep'].run(ts.cuda_stream)
+                with torch.cuda.stream(ts):
+                    o = self.out
+                    torch.mul(o['pose_cov_pred'], e['scale'], out=o['pose_cov_calib'])                       # (s s^T) * cov   (uncert_prop_pnp_optimizer.py:96-97)
+                    if e['sd'] > 0.0:                                                                       # cov_correction  (monorun_roi_head.py:530-534)
+                        o['pose_cov_calib'].mul_((e['sd'] / torch.norm(o['t_vec_pred'], p=2, dim=1)).square().view(-1, 1, 1))
+        elif self.B:
             with torch.cuda.device(self.dev):
                 st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
                 code = self.lib.mr_pnp_from_head_batched(*self.args, st)

@@ -314,6 +314,16 @@ def set_epnp_eig_mode(mode):
     lib().orc_set_epnp_eig_mode(ctypes.c_int(int(mode)))
 
 
+def set_epnp_refit_f64(on):
+    """Version-dependent decision (i) of epnp.inc: True (default) = solvePnPRansac's re-fit sees float64 normalised image points."""
+    lib().orc_set_epnp_refit_f64(ctypes.c_int(1 if on else 0))
+
+
+def set_lm_iter0_gradient_test(on):
+    """Version-dependent decision (iii): True (default) = Ceres tests the gradient tolerance before the first step."""
+    lib().orc_set_lm_iter0_gradient_test(ctypes.c_int(1 if on else 0))
+
+
 def svd_small(A):
     A = _d(A); m, n = A.shape
     w, u, v = np.zeros(n), np.zeros((m, n)), np.zeros((n, n))

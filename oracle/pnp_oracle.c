@@ -235,6 +235,8 @@ static int orc_householder_ls(int m, int n, double *A, double *b, double *y) {
     return 1;
 }
 
+static int orc_lm_iter0_gradient_test = 1;
+void orc_set_lm_iter0_gradient_test(int on) { orc_lm_iter0_gradient_test = on ? 1 : 0; }
 static void orc_lm_n_ex(int n, orc_eval_fn ev, orc_jac_fn jf, int nres, const void *ctx, const double *init, double *out,
                         orc_lm_summary *sm, orc_lm_opts *op) {
     const int    max_num_iterations = op->max_iter;
@@ -255,7 +257,7 @@ static void orc_lm_n_ex(int n, orc_eval_fn ev, orc_jac_fn jf, int nres, const vo
     double scale[ORC_MAXN];
     for (int j = 0; j < n; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[(n + 1) * j]));   /* jacobi_scaling, from the initial J */
     double x_norm = 0.0; for (int j = 0; j < n; ++j) x_norm += x[j] * x[j]; x_norm = sqrt(x_norm);
-    int last_successful = 1;        /* iteration 0 counts as successful (IterationZero sets it) */
+    int last_successful = orc_lm_iter0_gradient_test;   /* iteration 0 counts as successful (IterationZero sets it): version-dependent decision (iii), epnp.inc header */
     int iteration = 0, invalid_run = 0;
 
     for (;;) {
@@ -958,7 +960,7 @@ static int orc_epnp_init(const float *x2d, const float *x3d, uint8_t *mask, int 
         int ninl = 0; if (ok) for (int i = 0; i < n; ++i) ninl += rm[i];
         if (ok && ninl > 4) { for (int i = 0; i < n; ++i) mask[idx[i]] = rm[i]; n = ninl; }
     } else if (n >= 4) {
-        epnp_solve(o, im, n, K[0], K[4], K[2], K[5], R, tvec); epnp_rodrigues_to_vec(R, rvec); ok = 1;
+        epnp_solve(o, im, n, K[0], K[4], K[2], K[5], R, tvec, 0); epnp_rodrigues_to_vec(R, rvec); ok = 1;
     } else ok = 0;
     if (ok) { init_pose[0] = rvec[1]; init_pose[1] = tvec[0]; init_pose[2] = tvec[1]; init_pose[3] = tvec[2];
               ok = isfinite(init_pose[0]) && isfinite(init_pose[1]) && isfinite(init_pose[2]) && isfinite(init_pose[3]); }

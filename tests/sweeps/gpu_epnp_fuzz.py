@@ -13,6 +13,7 @@ def dv(a):
     t = torch.from_numpy(np.asarray(a)); d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev); d.copy_(t); return d
 bad = 0
 nobj = 0
+nbad_valid = 0
 for trial in range(int(os.environ.get('TRIALS', 40))):
     B = int(rng.choice([1, 3, 64, 200])); hw = int(rng.choice([3, 4, 8, 10, 28]))
     b = syn.make_batch(B=B, hw=hw, seed=int(rng.integers(1 << 30)))
@@ -50,4 +51,10 @@ for trial in range(int(os.environ.get('TRIALS', 40))):
     if not np.array_equal(valid, ref[0]):
         dd = np.flatnonzero(valid != ref[0])
         print('trial', trial, 'mode', mode, 'B', B, 'P', P, 'validity differs from the restatement for', len(dd), 'objects', dd[:5]); bad += 1
-print('EPnP fuzz done:', nobj, 'objects, problems:', bad)
+        nbad_valid += len(dd)
+        if os.environ.get('DETAIL'):
+            gd = out[5].cpu().numpy()
+            for o in dd[:3]:
+                print(f'    object {o}: restatement valid {bool(ref[0][o])} iters {ref[6][o, 0]:.0f} why {ref[6][o, 2]:.0f} cost {ref[6][o, 1]:.6g} | GPU valid {bool(valid[o])} iters {gd[o, 0]:.0f} why {gd[o, 2]:.0f} '
+                      f'cost {gd[o, 1]:.6g} | pose ref {ref[1][o].tolist() + ref[2][o].tolist()} gpu {pose[o].tolist()} | cov diag ref {np.diag(ref[3][o]).tolist()} gpu {np.diag(out[2][o].cpu().numpy()).tolist()}')
+print('EPnP fuzz done:', nobj, 'objects, trials with a problem:', bad, '; objects whose valid flag differs:', nbad_valid)

@@ -77,6 +77,77 @@ def test_sharded_solve_equals_single_process(world, n_objects):
         assert np.array_equal(out['cov'], cov) and np.array_equal(out['tr'], tr[:, 0]) and np.array_equal(out['valid'], ret)
 
 
+def _kitti_val_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('kitti_val', os.path.join(ROOT, 'tools', 'kitti_val.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _oracle_pose_stage(ob, lo, hi):
+    """Stand-in for the product's pose stage on CPU ranks: the numpy / C restatement of decode chain + PnP (tests may use the oracle)."""
+    from oracle import oracle as orc
+    lab = ob['labels'][lo:hi]
+    noc, ls, _ = orc.slice_pred(ob['all_pred'][lo:hi], lab, ob['flip'][lo:hi])
+    dims, dims_var = orc.dim_decode(ob['dim'][lo:hi], None, lab)
+    c3d, c3v = orc.noc_decode(noc, dims, dims_var)
+    ls_px = orc.decode_logstd(ls, c3v, exp=orc.spec_expf, log=orc.spec_logf)
+    x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(orc.roi_grid(ob['rois'][lo:hi]), ls_px, c3d, tuple(ob['hw'][lo]), exp=orc.spec_expf)
+    ret, yaw, t, cov, _, _ = orc.u2d_pnp(x2d, istd, x3d, np.ascontiguousarray(ob['K'][lo:hi]), ur, vr, 0.5, 0.6, thr, True, num_threads=1)
+    return dict(pose=torch.from_numpy(np.concatenate([yaw, t], 1)), cov=torch.from_numpy(cov), valid=torch.from_numpy(ret.astype(np.uint8)),
+                dims=torch.from_numpy(dims.astype(np.float32)))
+
+
+def _oracle_evaluate(results, infos, classes, filenames=None, result_dir=None):
+    """Stand-in for monorun_amd.evaluation.evaluate (a HIP evaluator) on CPU ranks: same formatting and result files, AP from the CPU
+    restatement of the KITTI protocol."""
+    from monorun_amd import evaluation as ev
+    from oracle import kitti_eval as ke
+    dts = ev.format_results(results, infos, classes)
+    os.makedirs(result_dir, exist_ok=True)
+    ev.write_result_files(dts, filenames, os.path.join(result_dir, 'data'))
+    ap = ke.kitti_ap([ev.format_gt_anno(i, classes) for i in infos], dts, classes, 'R40')
+    return ap, 'Car AP (CPU restatement) ' + repr({k: np.round(np.asarray(v, float), 6).tolist() for k, v in ap.items()}), dts
+
+
+def _harness_worker(rank, world, port, paths, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    kv = _kitti_val_module()
+    a = kv.parse_args(['--labels', paths['labels'], '--calib', paths['calib'], '--ids', paths['ids'], '--dumps', paths['dumps'],
+                       '--images-per-batch', '3', '--out', os.path.join(os.path.dirname(paths['ids']), f'out_w{world}')])
+    ap, text = kv.run(a, pose_fn=_oracle_pose_stage, backend='gloo', dev=torch.device('cpu'), evaluate_fn=_oracle_evaluate)
+    q.put((rank, text))
+
+
+def test_kitti_harness_world_2_equals_one_rank(tmp_path):
+    """tools/kitti_val.py's world > 1 branch (BASELINE config 4's shape): the objects of every batch of images split into contiguous
+    shards over the ranks, ONE packed all-gather (pose, covariance, validity, dimensions: 100-byte rows) per batch, evaluation on
+    rank 0 — run under gloo with two CPU ranks (uneven shards: 15 objects per batch, the last batch 5) and the CPU restatement as
+    the pose stage; the KITTI result text equals the one-rank run's."""
+    kv = _kitti_val_module()
+    paths = kv.write_synthetic_split(str(tmp_path / 'split'), 10, objs_per_img=5)
+    ctx = mp.get_context('spawn')
+    texts = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_harness_worker, args=(r, world, port, paths, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert all(res[r] is None for r in range(1, world))
+        texts[world] = res[0]
+    assert texts[1] is not None and 'Car AP' in texts[1] and texts[2] == texts[1]
+    assert sorted(os.listdir(tmp_path / 'split' / 'out_w2' / 'data')) == sorted(os.listdir(tmp_path / 'split' / 'out_w1' / 'data'))
+    for f in os.listdir(tmp_path / 'split' / 'out_w1' / 'data'):
+        assert (tmp_path / 'split' / 'out_w1' / 'data' / f).read_text() == (tmp_path / 'split' / 'out_w2' / 'data' / f).read_text()
+
+
 def test_shard_bounds_cover_everything_once():
     from monorun_amd.parallel import shard_bounds, PackedResults, ROW_BYTES
     for n in (0, 1, 7, 8, 1024, 65536):
@@ -87,6 +158,11 @@ def test_shard_bounds_cover_everything_once():
                 assert 0 <= hi - lo <= per and per == (n + w - 1) // w
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+    px = PackedResults(5, torch.device('cpu'), extra_f32=3)            # extra float columns ride in the same row
+    assert px.buf.numel() == 5 * (ROW_BYTES + 12) and px.extra.shape == (5, 3)
+    px.pose[:] = 1.5; px.extra[:] = 7.25; px.valid[:] = 1
+    ux = PackedResults.unpack(torch.cat([px.buf, px.buf]).view(2, -1), 8, extra_f32=3)
+    assert ux['extra'].shape == (8, 3) and (ux['extra'] == 7.25).all() and (ux['pose'] == 1.5).all() and ux['valid'].all()
     p = PackedResults(5, torch.device('cpu'))
     assert p.buf.numel() == 5 * ROW_BYTES and p.pose.shape == (5, 4) and p.cov.shape == (5, 4, 4)
     p.pose[:] = 1.5; p.cov[:] = 2.5; p.tr[:] = 3.5; p.valid[:] = 1

@@ -483,3 +483,56 @@ def test_k2_special_inputs_take_the_exact_path(dev, g3, orc):
     assert (~np.isfinite(got)).sum() > 0 and (got == 0).sum() > 0, 'the planted values did not reach the special cases'
     c3d = dec['coords_3d'].cpu().numpy()
     assert ((c3d.view(np.uint32) == c3d_ref.view(np.uint32)) | (np.isnan(c3d) & np.isnan(c3d_ref))).all()
+
+
+@pytest.mark.gpu
+def test_head_built_with_the_reference_initialiser_is_honoured_everywhere(dev, orc):
+    """a head whose pnp dict says initialiser='epnp' (the reference's flow: uncert_prop_pnp_optimizer.py:86-95 ->
+    pnp_uncert_cpu.py:33-68) gets that flow from every entry point — pose_from_head whatever `fused` says (the one-launch kernel only
+    knows K0, so both forms take K2 + module path), the prepared PoseFromHeadLaunch (K2 -> EPnP / RANSAC -> LM, also as a graph) and
+    u2d_pnp_cpu — and the result is the CPU restatement's: K2's decode chain -> u2d_pnp_epnp, masks bit-exact, pose within 1e-4."""
+    from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head, PoseFromHeadLaunch
+    from monorun_amd.ops import u2d_pnp_cpu
+    b = syn.make_batch(B=96, seed=41)
+    all_pred, dim = syn.encode_head_outputs(b, seed=41)
+    n_noc, n_ls, _ = orc.slice_pred(all_pred, b['labels'], False)
+    dims, _ = orc.dim_decode(dim, None, b['labels'])
+    c3d, _ = orc.noc_decode(n_noc, dims, None)
+    x2d, istd, x3d, ur, vr, thr = orc.pose_head_prep(orc.roi_grid(b['rois']), orc.decode_logstd(n_ls, None), c3d, b['img_shape'], exp=orc.spec_expf)
+    ref = orc.u2d_pnp_epnp(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
+    ref_k0 = orc.u2d_pnp(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
+    assert not np.array_equal(ref[5], ref_k0[5])                       # the two initialisers DO differ on this batch: the test can tell them apart
+    t = lambda a, dt=None: torch.from_numpy(np.asarray(a)).to(dev) if dt is None else torch.from_numpy(np.asarray(a)).to(device=dev, dtype=dt)
+    head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False,
+                                           initialiser='epnp')).to(dev)
+    args = (t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), (syn.IMG_H, syn.IMG_W, 3))
+
+    def check(res, what):
+        ok = ref[0]
+        assert np.array_equal(res['ret_val'].cpu().numpy(), ref[0]) and np.array_equal(res['inlier_mask'].cpu().numpy(), ref[5]), what
+        dyaw = np.abs(np.angle(np.exp(1j * (res['yaw_pred'].cpu().numpy() - ref[1]))))
+        assert ok.sum() >= 90 and dyaw[ok].max() <= 1e-4 and np.abs(res['t_vec_pred'].cpu().numpy() - ref[2])[ok].max() <= 1e-4, what
+    with torch.no_grad():
+        r_f = pose_from_head(head, *args, fused=True)
+        r_u = pose_from_head(head, *args, fused=False)
+    torch.cuda.synchronize()
+    check(r_f, 'pose_from_head(fused=True)'); check(r_u, 'pose_from_head(fused=False)')
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'inlier_mask', 'dimensions_pred'):
+        assert torch.equal(r_f[k], r_u[k]), k
+    # the prepared launch honours it too (it used to run K0 silently), eagerly and as a captured graph
+    pl = PoseFromHeadLaunch(head, *args)
+    out = pl.run(); torch.cuda.synchronize()
+    check(out, 'PoseFromHeadLaunch.run')
+    for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'inlier_mask', 'dimensions_pred'):
+        assert torch.equal(out[k], r_f[k]), k
+    assert torch.allclose(out['pose_cov_calib'], r_f['pose_cov_calib'], rtol=1e-6, atol=0)
+    keep = {k: out[k].clone() for k in ('pose', 'pose_cov_calib', 'inlier_mask_u8')}
+    out['pose'].zero_(); out['pose_cov_calib'].zero_(); out['inlier_mask_u8'].zero_()
+    pl.replay(); torch.cuda.synchronize()
+    assert all(torch.equal(out[k], keep[k]) for k in keep)
+    # ... and the numpy-level driver the reference's flow is written in
+    rr = u2d_pnp_cpu(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True, initialiser='epnp')
+    assert np.array_equal(rr[0], ref[0]) and np.array_equal(rr[5], ref[5])
+    assert np.abs(rr[2] - ref[2])[ref[0]].max() <= 1e-4 and np.abs(np.angle(np.exp(1j * (rr[1] - ref[1]))))[ref[0]].max() <= 1e-4
+    with pytest.raises(ValueError):
+        u2d_pnp_cpu(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True, initialiser='opencv')

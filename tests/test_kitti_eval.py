@@ -252,3 +252,9 @@ def test_gpu_end_to_end_harness_synthetic():
     bev = [float(v) for v in re.search(r'bev  AP:([\d.]+), ([\d.]+), ([\d.]+)', block).groups()]
     assert min(ap3d[1:]) > 80 and min(bev[1:]) > 80, text
     assert '40 images, 240 objects' in text
+    # the reference's initialiser restated on the GPU through the same harness (K2 -> EPnP / RANSAC -> LM per batch of images)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'kitti_val.py'), '--synthetic', '40', '--initialiser', 'epnp'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    block = out.stdout[out.stdout.index('Car AP@0.70, 0.50, 0.50'):]
+    ap3d = [float(v) for v in re.search(r'3d   AP:([\d.]+), ([\d.]+), ([\d.]+)', block).groups()]
+    assert min(ap3d[1:]) > 80 and "initialiser 'epnp'" in out.stdout

@@ -5,7 +5,7 @@
 # `roofline.achieved` is computed from) and 4 launches IN FLIGHT (the headline: the 2-waves-per-object kernel); plus the NOC path
 # (K2 decode, fused head->pose) and the EPnP/RANSAC initialiser.  Counters in their own --pmc passes (kernel trace only).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -56,6 +56,8 @@ if [[ " $PARTS " == *" epnp "* ]]; then
 prof epnp_trace "" -- env REPS=10 python $R/tools/gpu_epnp_path.py
 prof epnp_sq "$SQ1" -- env REPS=6 python $R/tools/gpu_epnp_path.py
 prof epnp_lds "$SQ2" -- env REPS=6 python $R/tools/gpu_epnp_path.py
+prof epnp_fetch "FETCH_SIZE" -- env REPS=6 python $R/tools/gpu_epnp_path.py
+prof epnp_write "WRITE_SIZE" -- env REPS=6 python $R/tools/gpu_epnp_path.py
 fi
 find $OUT -name "*.csv" | wc -l
 rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 > $OUT/rocminfo.txt

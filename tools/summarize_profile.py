@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', f'prof_{tag}')
 dst = os.path.join(root, 'profiles')
@@ -109,27 +109,36 @@ def epnp_block():
         launches.append(dict(position=i, kernel=seqs[0][i][0], grid_threads=seqs[0][i][2], avg_us=float(np.mean(d)), min_us=float(np.min(d)), max_us=float(np.max(d)), calls=len(d)))
     out = dict(launches=launches, initialiser_sum_us=float(sum(l['avg_us'] for l in launches if 'epnp_' in l['kernel'])),
                lm_launch_us=float(sum(l['avg_us'] for l in launches if 'pnp_uncert_kernel' in l['kernel'])))
-    # counters of the eigen launches: (name fragment, grid) -> block
-    eig = [l for l in launches if 'epnp_eig12_kernel' in l['kernel'] and l['avg_us'] > 20]
-    for tag, l in zip(('hypotheses_eigen', 'refit_eigen'), eig):
-        acc = collections.defaultdict(list)
-        for sub in ('epnp_sq', 'epnp_lds'):
-            g = find(sub, 'p_counter_collection.csv')
-            if not g:
-                continue
-            for r in csv.DictReader(open(g)):
-                if 'epnp_eig12_kernel' in r['Kernel_Name'] and int(r['Grid_Size']) == l['grid_threads']:
-                    acc[r['Counter_Name']].append(float(r['Counter_Value']))
-        c = {k: float(np.mean(v)) for k, v in acc.items()}
-        d = dict(kernel=l['kernel'], grid_threads=l['grid_threads'], avg_us=l['avg_us'], counters=c)
-        if c.get('SQ_WAVES'):
-            w = c['SQ_WAVES']
-            d['per_wave'] = {k: c[k] / w for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM') if k in c}
-            if 'SQ_WAVE_CYCLES' in c and 'SQ_ACTIVE_INST_ANY' in c:
-                d['active_frac_of_wave_cycles'] = c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES']
-            if c.get('SQ_LDS_IDX_ACTIVE'):
-                d['lds_bank_conflict_frac'] = c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE']
-        out[tag] = d
+    # per-kernel counters (means per launch; a kernel that runs in both rounds: the round-1 launches are the ones with work, the idle
+    # round-2 ones pull the mean down — both are listed by name only) and the HBM traffic of ONE call of the flow (all launches)
+    per_kernel = {}
+    for sub in ('epnp_sq', 'epnp_lds', 'epnp_fetch', 'epnp_write'):
+        g = find(sub, 'p_counter_collection.csv')
+        if not g:
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(g)):
+            if 'epnp_' in r['Kernel_Name'] or 'pnp_uncert_kernel' in r['Kernel_Name']:
+                acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+        for k, cs in acc.items():
+            per_kernel.setdefault(k.replace('(anonymous namespace)::', ''), {}).update({c: dict(mean=float(np.mean(v)), sum=float(np.sum(v)), launches=len(v)) for c, v in cs.items()})
+    out['counters_per_kernel'] = per_kernel
+    calls = None
+    for k, cs in per_kernel.items():
+        if 'epnp_front_kernel' in k and 'FETCH_SIZE' in cs:
+            calls = cs['FETCH_SIZE']['launches']
+    if calls:
+        fetch = sum(cs['FETCH_SIZE']['sum'] for cs in per_kernel.values() if 'FETCH_SIZE' in cs) / calls
+        write = sum(cs['WRITE_SIZE']['sum'] for cs in per_kernel.values() if 'WRITE_SIZE' in cs) / calls
+        out['traffic'] = dict(hbm_bytes_per_call=(2 * fetch + write) * 1024, fetch_size_kb_raw_per_call=fetch, write_size_kb_raw_per_call=write, calls=calls,
+                              fetch_correction='x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section)',
+                              what='all launches of one call of the reference flow (initialiser + LM) on 1024 config-2 objects')
+    for k, cs in per_kernel.items():
+        if 'SQ_WAVES' in cs and cs['SQ_WAVES']['mean'] > 0:
+            w = cs['SQ_WAVES']['mean']
+            cs['per_wave'] = {c: cs[c]['mean'] / w for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM') if c in cs}
+            if 'SQ_WAVE_CYCLES' in cs and 'SQ_ACTIVE_INST_ANY' in cs:
+                cs['active_frac_of_wave_cycles'] = cs['SQ_ACTIVE_INST_ANY']['mean'] / cs['SQ_WAVE_CYCLES']['mean']
     return out
 
 
@@ -155,7 +164,7 @@ summ = dict(tag=tag,
             fused_head_to_pose=kernel_block('noc_fused', 'pnp_uncert_kernel', passes=('fetch', 'write', 'sq'), trace='noc_fused_trace',
                                             alg_bytes=B * (P * 20 + 52 + 85 + P + 64 + 24)),
             epnp_stages=epnp_block(),
-            bench_kernel_avg_us=b['roofline']['kernel_ms_avg'] * 1e3, bench_value=b['value'], bench_single_stream=b.get('single_stream', {}).get('value'))
+            bench_kernel_avg_us=b['roofline']['isolated_launch']['kernel_ms_avg'] * 1e3, bench_value=b['value'], bench_single_stream=b.get('single_stream', {}).get('value'))
 json.dump(summ, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
 t1 = summ['single_stream'].get('traffic')
 if t1:
@@ -170,5 +179,14 @@ for k in ('single_stream', 'in_flight', 'k2_noc_decode', 'fused_head_to_pose'):
 ep = summ['epnp_stages']
 for l in ep.get('launches', []):
     print('epnp launch %2d %-70s avg us %7.1f' % (l['position'], l['kernel'].replace('(anonymous namespace)::', '')[:70], l['avg_us']))
-print('initialiser sum us %.1f, LM launch %.1f' % (ep.get('initialiser_sum_us', 0), ep.get('lm_launch_us', 0)), 'hypotheses eigen per wave', json.dumps(ep.get('hypotheses_eigen', {}).get('per_wave')))
+print('initialiser sum us %.1f, LM launch %.1f' % (ep.get('initialiser_sum_us', 0), ep.get('lm_launch_us', 0)), 'traffic per call', json.dumps(ep.get('traffic')))
+if ep.get('traffic'):
+    json.dump(dict(tag=tag, **ep['traffic'], algorithmic_bytes_per_call=alg, ratio_traffic_over_algorithmic=ep['traffic']['hbm_bytes_per_call'] / alg,
+                   source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_epnp_path.py (tools/profile_round.sh {tag})'),
+              open(os.path.join(dst, f'{tag}_epnp_traffic.json'), 'w'), indent=1)
+with open(os.path.join(dst, f'{tag}_epnp_launches.txt'), 'w') as f:
+    f.write('the launches of one call of the reference flow on 1024 config-2 objects (batch 0), rocprofv3 kernel trace, averaged over the calls of the trace\n')
+    for l in ep.get('launches', []):
+        f.write('%2d %-72s avg %7.1f us  min %7.1f  max %7.1f\n' % (l['position'], l['kernel'].replace('(anonymous namespace)::', '').replace('void ', '')[:72], l['avg_us'], l['min_us'], l['max_us']))
+    f.write('initialiser sum %.1f us, LM launch %.1f us\n' % (ep.get('initialiser_sum_us', 0), ep.get('lm_launch_us', 0)))
 print('bench events avg us', summ['bench_kernel_avg_us'], 'value', b['value'], 'single_stream', summ['bench_single_stream'])
