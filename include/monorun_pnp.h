@@ -60,8 +60,9 @@ extern "C" {
 #define MR_COV_NONE           0x8     /* do not compute the pose covariance (cov left untouched) */
 #define MR_COV_CERES          0x10    /* covariance with the solver's (Ceres/autodiff) Jacobian instead of the
                                          torch Jacobian of jacobian.py (what `pnp_uncert`'s result_cov is) */
-#define MR_ANY_ORDER          0x20    /* the launch may start before earlier work on the same stream has finished (hipExtAnyOrderLaunch:
-                                         no barrier bit on the dispatch); the caller orders consumers with events.  Experimental */
+#define MR_ANY_ORDER          0x20    /* mr_pnp_uncert_batched ONLY (every other entry point ignores the bit): the launch may start before earlier
+                                         work on the same stream has finished (hipExtAnyOrderLaunch: no barrier bit on the dispatch); the caller
+                                         orders consumers with events.  Experimental */
 #define MR_WAVES_SHIFT        8       /* bits 8..11: wavefronts cooperating on one object (0 = auto, 1,2,4,8) */
 #define MR_WAVES_MASK         (0xF << MR_WAVES_SHIFT)
 #define MR_LM_MAXIT_SHIFT      16      /* bits 16..21: Ceres' max_num_iterations for the LM (0 = the default, 50; 1..63) */
@@ -90,6 +91,10 @@ int mr_pnp_version(void);
 const char *mr_pnp_error_string(int code);
 int mr_pnp_last_hip_error(void);
 int mr_pnp_device_count(void);
+/* waves per object the library picks for `objects_in_flight` objects x P points on the current device (its rule for one launch of that
+ * many objects); a caller with several launches in flight passes the objects of ALL of them and puts the answer into MR_WAVES bits.
+ * Returns 1, 2 or 4, or a negative MR_ERR_* code. */
+int mr_pick_waves(int objects_in_flight, int P);
 /* one wavefront busy for `microseconds` on `stream` (stream-overlap self-test of the Python pipeline; asynchronous) */
 int mr_spin(int microseconds, void *stream);
 
@@ -140,11 +145,16 @@ int mr_pnp_uncert_batched(
  * diag (B,4) f32 or NULL [RANSAC iterations run, inliers of the best model, candidates, index of the best model],
  * debug_hypotheses (B,30,12) f64 or NULL (every hypothesis' R | t; tests).  Feed the three outputs to
  * mr_pnp_uncert_from_init_batched for the LM + covariance.
- * The call is a sequence of launches on `stream` (sample set-up; speculative hypotheses in two rounds — MR_EPNP_FIRST_ROUND — each M^T M,
- * 12x12 eigen-problems, poses, consensus + OpenCV's sequential loop replayed over the counts; the re-fit) that hand their intermediate results over in
+ * The call is a sequence of seven launches on `stream` (sample set-up; speculative hypotheses in two rounds — MR_EPNP_FIRST_ROUND — one
+ * launch per round that takes a sample to its three candidate poses, consensus + OpenCV's sequential loop replayed over the counts; the
+ * re-fit's eigenvectors + beta candidates; the re-fit) that hand their intermediate results over in
  * `workspace`: device memory of at least mr_epnp_workspace_bytes(B, P) bytes, 256-byte aligned, owned by the caller and free to be
- * reused once the work queued on `stream` has passed it (65 MB per 1024 objects).  workspace = NULL: the library takes it from the
- * device's default memory pool for the duration of the call (hipMallocAsync / hipFreeAsync on `stream`).
+ * reused once the work queued on `stream` has passed it (17 MB per 1024 objects).  workspace = NULL: the library takes it from a
+ * stream-ordered memory pool OF ITS OWN (one per device, created on first use, freed blocks kept for the next call: hipMallocFromPoolAsync /
+ * hipFreeAsync on `stream`); the process's default pool and its attributes are not touched.  Pass a workspace for steady-state use.
+ * LIMITATIONS (oracle/epnp.inc "version-dependent decisions"): with thresholds, an object with exactly FOUR candidates (only possible
+ * when P = 4) is reported as an initialiser failure — OpenCV would solve it with P3P (model_points = 4), which is not restated; P >= 5
+ * is unaffected (fewer than five istd candidates fall back to all P points).  MR_EPNP_REFIT_F32 selects round 3's float32 re-fit.
  */
 int mr_epnp_ransac_batched(
     const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,

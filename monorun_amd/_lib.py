@@ -67,6 +67,8 @@ def load():
     lib.mr_pnp_last_hip_error.restype = i32
     lib.mr_pnp_device_count.restype = i32
     lib.mr_spin.restype = i32
+    lib.mr_pick_waves.restype = i32
+    lib.mr_pick_waves.argtypes = [i32, i32]
     lib.mr_spin.argtypes = [i32, vp]
     lib.mr_pnp_uncert_batched.restype = i32
     lib.mr_pnp_uncert_batched.argtypes = [
@@ -132,6 +134,6 @@ def check(code):
                            f'(code {code}, hip error {lib.mr_pnp_last_hip_error()})')
 
 
-EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_spin', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
+EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_spin', 'mr_pick_waves', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
                     'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
                     'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

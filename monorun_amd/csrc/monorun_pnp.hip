@@ -683,7 +683,7 @@ size_t lds_bytes(const PnpArgs &a, int wpo) {
     const bool small = wpo <= 2;                           // one- and two-wave instantiations: 12-byte B records at fp32, one index list (pnp_kernel.inc)
     n += (size_t)((small && a.elem_size == 4) ? 7 : 8) * a.P * a.elem_size;      // point records
     n += (small ? 1 : 2) * sizeof(uint16_t) * ((a.P + 7) & ~7);                   // candidate list (+ final inlier list)
-    n += small ? sizeof(unsigned long long) * a.nca : (size_t)a.P;               // inlier mask: one bit or one byte per point
+    n += small ? sizeof(unsigned long long) * a.nca + 8 : (size_t)a.P;           // inlier mask: one bit (64-bit words on an 8-byte boundary: up to 4 bytes of padding) or one byte per point
     return (n + 15) & ~(size_t)15;
 }
 
@@ -903,20 +903,29 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
     bool own = false;
     if (base) { if (workspace_bytes < need || ((uintptr_t)base & 255)) return MR_ERR_BAD_ARGUMENT; }
     else {
-        static std::mutex mu; static bool pool_kept[kMaxDevices] = {};
+        // a PRIVATE stream-ordered pool per device (the process's default pool is left as it is): freed workspaces stay in it across
+        // synchronisations (release threshold = max), so the steady state allocates nothing
+        static std::mutex mu; static hipMemPool_t pools[kMaxDevices] = {};
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= kMaxDevices) return MR_ERR_UNSUPPORTED;
+        hipMemPool_t pool;
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (dev >= 0 && dev < kMaxDevices && !pool_kept[dev]) {       // keep freed blocks in the pool across synchronisations
-                hipMemPool_t pool;
-                HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+            if (!pools[dev]) {
+                hipMemPoolProps props;
+                memset(&props, 0, sizeof props);
+                props.allocType = hipMemAllocationTypePinned;
+                props.handleTypes = hipMemHandleTypeNone;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = dev;
+                HIP_TRY(hipMemPoolCreate(&pools[dev], &props));
                 uint64_t keep = ~0ull;
-                HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-                pool_kept[dev] = true;
+                HIP_TRY(hipMemPoolSetAttribute(pools[dev], hipMemPoolAttrReleaseThreshold, &keep));
             }
+            pool = pools[dev];
         }
-        HIP_TRY(hipMallocAsync((void **)&base, need, st));
+        HIP_TRY(hipMallocFromPoolAsync((void **)&base, need, pool, st));
         own = true;
     }
     epnp_work_bytes(a.B, a.P, &ea.w, base);
@@ -980,6 +989,13 @@ int mr_spin(int microseconds, void *stream) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
     HIP_TRY(hipGetLastError());
     return MR_OK;
+}
+
+// waves per object the library would pick for a launch of `objects_in_flight` objects x P points on the current device (pick_wpo): lets
+// a caller that keeps several launches in flight apply the library's own rule to ALL the objects on the chip (PnPPipeline.flags_for)
+int mr_pick_waves(int objects_in_flight, int P) {
+    if (objects_in_flight < 1 || P < 4) return MR_ERR_BAD_ARGUMENT;
+    return pick_wpo(objects_in_flight, P, 0);
 }
 
 int mr_pnp_device_count(void) {

@@ -306,8 +306,8 @@ class PnPPipeline:
             for _ in range(3):
                 a.synchronize(); b.synchronize()
                 t0 = time.perf_counter()
-                lib.mr_spin(US, a.cuda_stream)
-                lib.mr_spin(US, b.cuda_stream)
+                _lib.check(lib.mr_spin(US, a.cuda_stream))
+                _lib.check(lib.mr_spin(US, b.cuda_stream))
                 a.synchronize(); b.synchronize()
                 best = min(best, time.perf_counter() - t0)
             return best * 1e6
@@ -337,14 +337,11 @@ class PnPPipeline:
         wavefronts per object from ONE launch's size (4 up to B = 2048, 2 beyond: more waves shorten an object's latency chain,
         fewer cost fewer instructions per object); with `depth` launches in flight the chip holds depth x B objects, so the same
         rule is applied to that number (measured on MI355X, 1024-object launches, depth 4: 34 instead of 30 M solves/s)."""
-        eff = int(B) * self.depth
-        w = 1
-        while w < 4 and eff * w * 2 <= 8192 and P >= 64 * w * 2:
-            w *= 2
-        wp = 1
-        while wp < 4 and P > 64 * wp * 8:
-            wp *= 2
-        return max(w, wp) << _lib.MR_WAVES_SHIFT
+        with torch.cuda.device(self.dev):
+            w = int(_lib.load().mr_pick_waves(int(B) * self.depth, int(P)))       # the library's own rule (device properties included)
+        if w < 0:
+            _lib.check(w)
+        return w << _lib.MR_WAVES_SHIFT
 
     def submit(self, launch, slot=None, after=None):
         k = (self._next if slot is None else int(slot)) % self.depth
