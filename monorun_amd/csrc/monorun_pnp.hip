@@ -1227,7 +1227,9 @@ int mr_noc_decode_batched(
     const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) &&
                     ((((uintptr_t)all_pred | (uintptr_t)coords_2d | (uintptr_t)coords_2d_istd | (uintptr_t)coords_3d) & 15) == 0);
     if (x4) {
-        // 256 threads x one quad measured best (13.1 us per 1024 x 28x28 batch; 128 x 2 quads 14.2, 64 x 4 quads 25.5: the kernel wants threads, not trips)
+        // 256 threads x one quad measured best (13.1 us per 1024 x 28x28 batch; 128 x 2 quads 14.2, 64 x 4 quads 25.5: the kernel wants threads, not trips);
+        // a persistent, three-stage software-pipelined form (loads of the next quad in flight during the arithmetic; bit-identical outputs) is NOT faster:
+        // 13.0 - 14.9 us against 12.5 in the same session (tools/ubench/k2_pipelined_experiment.inc, profiles/r04_k2_pipelined_experiment.txt)
         hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4);
         HIP_TRY(hipGetLastError());
         return MR_OK;
