@@ -730,7 +730,7 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
         from monorun_amd import PnPEpnpLaunch, PnPPipeline
         mk_ep = lambda bi, fl=0: PnPEpnpLaunch(*dev_batches[bi % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=dev_batches[bi % NB][6],
                                                inlier_opt_only=True, flags=fl)
-        nrot = min(NB, 4)
+        nrot = NB                     # every resident batch: ~15 % of config-2 batches hold an object whose RANSAC loop wants more than the 8 first-round hypotheses
         le1 = [mk_ep(i) for i in range(nrot)]
         for l in le1:
             l.run()
@@ -775,19 +775,21 @@ def secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, 
         # the same flow with prepared launches in flight (PnPPipeline): the stages are latency chains, several batches overlap
         pipe = PnPPipeline(dev, depth=4, record_events=False)
         nl = max(pipe.depth, 1)
-        le = [mk_ep(i, pipe.flags_for(B_PER_GPU, P)) for i in range(nl)]       # the LM launch with the waves per object the pipeline asks for
-        for i in range(2 * nl):
-            pipe.submit(le[i % nl], slot=i % nl)
+        nobj = ((max(NB, nl) + nl - 1) // nl) * nl                              # launch objects: a multiple of the depth, so that object i always lands on stream i % depth
+        le = [mk_ep(i, pipe.flags_for(B_PER_GPU, P)) for i in range(nobj)]     # the LM launch with the waves per object the pipeline asks for
+        for i in range(nobj):
+            pipe.submit(le[i], slot=i % nl)
         pipe.drain()
-        nf = max(40, 2 * args.steps)
+        nf = max(96, 4 * args.steps)
+        nf -= nf % nobj
         t1 = time.perf_counter()
         for i in range(nf):
-            pipe.submit(le[i % nl], slot=i % nl)
+            pipe.submit(le[i % nobj], slot=(i % nobj) % nl)
         pipe.drain()
         el = time.perf_counter() - t1
         same = bool(torch.equal(le[0].pose, ref[1]) and torch.equal(le[0].mask, ref[4]) and torch.equal(le[0].valid, ref[0]))
         ep['in_flight'] = {'value': B_PER_GPU * nf / el, 'unit': 'solves/s', 'ms_per_step': el / nf * 1e3, 'launches_in_flight': nl, 'steps': nf,
-                           'distinct_batches': min(nl, NB), 'outputs_equal_the_one_at_a_time_results': same,
+                           'distinct_batches': min(nobj, NB), 'outputs_equal_the_one_at_a_time_results': same,
                            'what': 'PnPEpnpLaunch objects (initialiser + LM, own workspace and outputs) submitted round-robin to PnPPipeline'}
         # roofline of the flow: the algorithmic bytes are config 2's (every correspondence read once, the outputs written once); the
         # launches re-read the tile (front, consensus, re-fit, LM: 4 x) and hand over through a 17 MB workspace — HBM traffic from the

@@ -7,9 +7,9 @@ from monorun_amd import synthetic as syn, PnPEpnpLaunch, PnPPipeline
 dev = torch.device('cuda:0')
 def dv(a):
     t = torch.from_numpy(np.asarray(a)); d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev); d.copy_(t); return d
-NB = 4
+NB = int(os.environ.get('NBATCH', 12))
 batches = [[dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=1234 + 7919 * i), planar=True)] for i in range(NB)]
-tag = os.environ.get('MR_PNP_SO', 'default').split('/')[-1]
+tag = os.environ.get('MR_PNP_SO', 'default').split('/')[-1] + ' first_round=' + os.environ.get('MR_EPNP_FIRST_ROUND', '8')
 for depth in (1, 4):
     pipe = PnPPipeline(dev, depth=depth, record_events=False)
     le = [PnPEpnpLaunch(*batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=batches[i % NB][6], inlier_opt_only=True,
@@ -20,9 +20,9 @@ for depth in (1, 4):
             pipe.submit(le[i % len(le)], slot=i % len(le))
         pipe.drain(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(40):
+        for i in range(96):
             pipe.submit(le[i % len(le)], slot=i % len(le))
         pipe.drain()
-        res.append(1024 * 40 / (time.perf_counter() - t0) / 1e6)
+        res.append(1024 * 96 / (time.perf_counter() - t0) / 1e6)
     print(f'{tag}: depth {depth}: ' + ' '.join(f'{r:5.2f}' for r in res) + f'  median {np.median(res):.2f} M solves/s; pose checksum {sum(float(l.pose.double().sum()) for l in le):.9f}', flush=True)
     del pipe, le
