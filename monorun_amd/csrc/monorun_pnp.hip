@@ -945,10 +945,12 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             const int nh = ea.h1 - ea.h0;
             if (nh <= 0) break;
             const long long quads = (long long)a.B * nh;
+            // 16 quads per single-wave workgroup: 8 / 4 per wave (more waves, fewer matrices in lockstep) measured 74 / 140 us against 74 us one call
+            // at a time and 5.4 / 4.1 against 6.3 M solves/s in flight (profiles/r04_epnp_quads_per_wave.txt)
             hipLaunchKernelGGL(epnp_hyp_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(64), 0, st, ea);
             hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
         }
-        hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);
+        hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);      // (8 / 4 / 2 quads per wave: 67 / 68 / 102 us against 55 us)
         hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
         HIP_TRY(hipGetLastError());
         return MR_OK;
