@@ -385,3 +385,39 @@ def test_reference_flow_on_more_than_65535_objects_in_one_call(dev):
         for n in ('init_pose', 'init_mask', 'init_valid', 'pose', 'mask', 'valid'):
             assert torch.equal(getattr(big, n)[s], getattr(l, n)), (i, n)
         assert torch.allclose(big.cov[s], l.cov, rtol=1e-5, atol=0.0), i
+
+
+def test_refit_normalisation_switch_mirrors_the_restatement(dev, orc):
+    """oracle/epnp.inc, version-dependent decision (i): solvePnPRansac's final re-fit sees float64 normalised image points (default
+    since round 4) or float32 ones (round 3's reading, MR_EPNP_REFIT_F32 / orc.set_epnp_refit_f64(False)).  The kernel follows the
+    restatement either way: RANSAC masks identical (they are decided before the re-fit), start pose to INIT_TOL; and the two readings
+    differ from each other (the switch is live) by far less than the 1e-4 bar after the LM."""
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    b = syn.make_batch(B=48, seed=913)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    d = [_t(dev, a) for a in (x2d, istd, x3d, K, thr)]
+    got = {}
+    for f64 in (True, False):
+        orc.set_epnp_refit_f64(f64)
+        try:
+            refs = _stage_reference(orc, x2d, istd, x3d, K, thr)
+        finally:
+            orc.set_epnp_refit_f64(True)
+        gpu = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[4], with_diag=True, debug_hypotheses=True,
+                                 flags=0 if f64 else _lib.MR_EPNP_REFIT_F32)
+        torch.cuda.synchronize()
+        _check_stage(gpu, refs)
+        got[f64] = gpu[0].cpu().numpy()
+    dd = np.abs(got[True] - got[False]).max()
+    assert 0.0 < dd < 1e-2, dd
+
+
+def test_library_wave_rule_is_exported(dev):
+    """mr_pick_waves: the library's own rule for waves per object, which PnPPipeline.flags_for applies to all objects in flight."""
+    from monorun_amd import _lib, PnPPipeline
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        assert lib.mr_pick_waves(1024, 784) == 4 and lib.mr_pick_waves(4096, 784) == 2 and lib.mr_pick_waves(0, 784) < 0
+    pipe = PnPPipeline(dev, depth=4, verify=False)
+    assert pipe.flags_for(1024, 784) == 2 << _lib.MR_WAVES_SHIFT

@@ -234,3 +234,27 @@ def test_k0_agrees_with_the_reference_initialiser_after_lm(orc, seed):
     assert np.nanquantile(s['maha'][sm], 0.99) <= 0.05 and np.quantile(s['d'][sm], 0.5) <= 1e-3
     assert np.mean(s['maha'][sm] > 0.1) <= 0.01 and np.nanmax(s["maha"][sm]) <= 5.0
     assert np.nanmax(s["maha"][df]) <= 5.0 and np.nanquantile(s['maha'][df], 0.5) <= 0.1  # different sets: well inside 1 sigma
+
+
+def test_version_dependent_decisions_are_switches(orc):
+    """oracle/epnp.inc header, "version-dependent decisions": (i) the re-fit's normalised image points in float64 (default) or float32,
+    (iii) Ceres' gradient test before the first step — each is a live switch, and on config-2 data neither moves a pose by anywhere
+    near the 1e-4 bar (profiles/r04_epnp_version_choices.txt has the 8 192-object sweep)."""
+    b = syn.make_batch(B=64, seed=2024)
+    x2d, istd, x3d, Km, ur, vr, thr = [np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)]
+    run = lambda: orc.u2d_pnp_epnp(x2d, istd, x3d, Km, ur, vr, 0.5, 0.6, thr, True, return_init=True)
+    base = run()
+    orc.set_epnp_refit_f64(False)
+    try:
+        f32 = run()
+    finally:
+        orc.set_epnp_refit_f64(True)
+    assert np.array_equal(base[5], f32[5]) and np.array_equal(base[0], f32[0])                 # masks are decided before the re-fit
+    d_init = np.abs(base[6] - f32[6]).max()
+    assert 0.0 < d_init < 1e-2 and np.abs(base[2] - f32[2]).max() <= 1e-4
+    orc.set_lm_iter0_gradient_test(False)
+    try:
+        g0 = run()
+    finally:
+        orc.set_lm_iter0_gradient_test(True)
+    assert np.array_equal(base[2], g0[2]) and np.array_equal(base[1], g0[1])                   # no config-2 start is already stationary
