@@ -10,7 +10,7 @@ def dv(a):
 NB = int(os.environ.get('NBATCH', 12))
 batches = [[dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=1234 + 7919 * i), planar=True)] for i in range(NB)]
 tag = os.environ.get('MR_PNP_SO', 'default').split('/')[-1] + ' first_round=' + os.environ.get('MR_EPNP_FIRST_ROUND', '8')
-for depth in (1, 4):
+for depth in [int(v) for v in os.environ.get('DEPTHS', '1,4').split(',')]:
     pipe = PnPPipeline(dev, depth=depth, record_events=False)
     le = [PnPEpnpLaunch(*batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=batches[i % NB][6], inlier_opt_only=True,
                         flags=pipe.flags_for(1024, 784) if depth > 1 else 0) for i in range(max(depth, NB))]
