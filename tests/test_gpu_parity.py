@@ -562,3 +562,29 @@ def test_reference_eigenvalue_rule_for_ill_conditioned_hessians(dev, orc):
     assert outs[False][0][:6].all() and not outs[True][0][:6].any(), 'the six degenerate objects are valid without the rule and dropped by it'
     assert np.array_equal(outs[True][3][~outs[True][0]], np.broadcast_to(np.eye(4, dtype=np.float32), (int((~outs[True][0]).sum()), 4, 4)))
     assert outs[True][0][6:].sum() >= 16
+
+
+def test_bench_line_describes_the_regime_it_measured():
+    """bench.py's ONE JSON line: the top-level roofline is the timed regime's (kernel instantiation and launches in
+    flight named, chip-level bytes / wall), the isolated-launch figures sit under `isolated_launch`, `steady_state` and the reference's
+    own flow (`reference_flow`: one call at a time, in flight, its roofline) ride in the line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '8', '--warmup', '2', '--batches', '4', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-500:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d['metric'].startswith('PnP solves/sec') and d['unit'] == 'solves/s' and d['dtype'] == 'f64' and d['n_gpus'] == 1 and d['steps'] == 8
+    rf = d['roofline']
+    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and rf['kernel'].startswith('pnp_uncert_kernel<float, ') and rf['launches_in_flight'] >= 1
+    chip = d['value'] * rf['algorithmic_bytes_per_launch'] / 1024 / 1e9                   # algorithmic bytes of all launches / wall time
+    assert abs(rf['achieved'] - chip) <= 1e-6 * chip and abs(rf['frac'] - chip / 8000.0) <= 1e-9
+    iso = rf['isolated_launch']
+    assert iso['kernel_ms_avg'] > 0 and abs(iso['frac'] - rf['algorithmic_bytes_per_launch'] / (iso['kernel_ms_avg'] * 1e-3) / 1e9 / 8000.0) <= 1e-9
+    assert d['steady_state']['steps'] >= 240 and d['steady_state']['value'] > 0 and d['single_stream']['value'] > 0
+    ref = d['reference_flow']
+    assert ref['value'] > 0 and ref['in_flight']['value'] > 0 and ref['synchronous_call']['value'] > 0
+    assert ref['roofline']['algorithmic_bytes_per_call'] == rf['algorithmic_bytes_per_launch'] and 0 < ref['roofline']['frac'] < 1
+    assert d['secondary_throughput']['epnp_initialiser']['outputs_equal_the_eager_op'] is True
+    assert ref['in_flight']['outputs_equal_the_one_at_a_time_results'] is True and d['outputs_verified'] is True
