@@ -370,16 +370,18 @@ def test_fp64_storage_gives_the_fp32_results(dev):
 
 def test_reference_flow_on_more_than_65535_objects_in_one_call(dev):
     """One call over 73 728 objects (no grid dimension of the initialiser's launches is limited to 65 535 workgroups; a 5.3 GB workspace):
-    initial poses, RANSAC masks, final poses and masks of every object equal those of 1 024-object calls on the same data (the covariance to
-    float32 summation order: the LM launch picks its waves per object by batch size)."""
-    from monorun_amd import PnPEpnpLaunch
+    initial poses, RANSAC masks, final poses, covariances and masks of every object equal those of 1 024-object calls on the same data, bit
+    for bit (both with four waves per object in the LM launch: left to itself the library picks the waves per object by batch size, and
+    the lanes' summation order — hence the last bit of a pose now and then — follows it)."""
+    from monorun_amd import PnPEpnpLaunch, _lib
     parts = [[torch.from_numpy(np.asarray(a)).to(dev) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=900 + i), planar=False)] for i in range(4)]
-    small = [PnPEpnpLaunch(*b[:6], epnp_ransac_thres=b[6], inlier_opt_only=True) for b in parts]
+    w4 = 4 << _lib.MR_WAVES_SHIFT
+    small = [PnPEpnpLaunch(*b[:6], epnp_ransac_thres=b[6], inlier_opt_only=True, flags=w4) for b in parts]
     for l in small:
         l.run()
     reps = 18                                                      # 4 x 18 x 1024 = 73 728 objects
     cat = lambda j: torch.cat([parts[i % 4][j] for i in range(4 * reps)], 0)
-    big = PnPEpnpLaunch(cat(0), cat(1), cat(2), parts[0][3], parts[0][4], parts[0][5], epnp_ransac_thres=cat(6), inlier_opt_only=True)
+    big = PnPEpnpLaunch(cat(0), cat(1), cat(2), parts[0][3], parts[0][4], parts[0][5], epnp_ransac_thres=cat(6), inlier_opt_only=True, flags=w4)
     big.run()
     torch.cuda.synchronize()
     assert big.pose.shape[0] == 73728 and int(big.valid.sum()) > 70000
