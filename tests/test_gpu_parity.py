@@ -588,3 +588,5 @@ def test_bench_line_describes_the_regime_it_measured():
     assert ref['roofline']['algorithmic_bytes_per_call'] == rf['algorithmic_bytes_per_launch'] and 0 < ref['roofline']['frac'] < 1
     assert d['secondary_throughput']['epnp_initialiser']['outputs_equal_the_eager_op'] is True
     assert ref['in_flight']['outputs_equal_the_one_at_a_time_results'] is True and d['outputs_verified'] is True
+    pw = d['config']['prewarm']                                # the untimed pre-conditioning is reported, with the window as a cold process sees it
+    assert pw['launches'] > 0 and pw['ms'] >= pw['ms_asked'] and pw['window_before']['steps'] == 8 and pw['window_before']['value'] > 0
