@@ -399,22 +399,26 @@ def run(args):
     # Device pre-conditioning, untimed and reported (config.prewarm): a process that has just started finds the GPU in its idle power
     # state, and the driver's 20-step window (~0.6 ms) is over before the clocks have come up — measured: the same window is 8 - 9 %
     # slower in a fresh process than after ~40 ms of launches (profiles/r04_closing_schedule_experiment.txt).  A serving process is
-    # never in that state, so the hot path is run for MR_BENCH_PREWARM_MS (default 60) through the same pipeline first; the W warm-up
-    # steps of the contract follow as before.
-    prewarm_ms = float(os.environ.get('MR_BENCH_PREWARM_MS', '60'))
-    prewarm = {'ms_asked': prewarm_ms, 'launches': 0, 'ms': 0.0}
-    if prewarm_ms > 0:
+    # never in that state, so MR_BENCH_PREWARM_LAUNCHES (default 2048, ~ 60 ms) launches of the hot path are issued through the same
+    # pipeline first; the W warm-up steps of the contract follow as before.
+    prewarm_n = int(os.environ.get('MR_BENCH_PREWARM_LAUNCHES', '2048'))
+    if os.environ.get('MR_BENCH_PREWARM_MS') == '0':
+        prewarm_n = 0
+    prewarm = {'launches_asked': prewarm_n, 'launches': 0, 'ms': 0.0}
+    if prewarm_n > 0:
         # the same K-step window first, as a just-started process sees it (reported beside `value`, never as `value`)
         cold = Loop(L, G_MAIN).timed(args.steps, args.warmup)
         prewarm['window_before'] = {'steps': args.steps, 'warmup': args.warmup, 'value': B_PER_GPU * world * args.steps / cold, 'unit': 'solves/s',
                                     'what': 'the timed window as measured BEFORE the pre-conditioning (idle clocks), same loop, same steps'}
-        pl = Loop(L, 1 if not use_dist else G_MAIN)
+        # a FIXED number of launches (every rank does the same; no collective in here), through the pipeline of the timed loop
+        pp = pipe_of(L_ASKED)
         t0 = time.perf_counter()
-        while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
-            for _ in range(S):
-                pl.step()
-            pl.fence()
+        for blk in range((prewarm_n + S - 1) // S):
+            for sl in range(S):
+                pp.submit(launches[(blk * S + sl) % NB][sl], slot=sl)
+            pp.drain()
             prewarm['launches'] += S
+        torch.cuda.synchronize()
         prewarm['ms'] = (time.perf_counter() - t0) * 1e3
     main_loop = Loop(L, G_MAIN)
     elapsed = main_loop.timed(args.steps, args.warmup)
@@ -568,7 +572,7 @@ def run(args):
                        'issue': (f'steps issued round-robin on {L} HIP streams by monorun_amd.PnPPipeline (one completion event per result buffer); '
                                  'every step is one full 1024-object launch into its own buffers, all outputs complete inside the timed window '
                                  'and verified bit-identical to isolated launches after it') if L > 1 else 'one stream: every launch waits for the previous one',
-                       'prewarm': dict(prewarm, what='untimed launches of the same hot path before the W warm-up steps, so that the timed window does not start on idle clocks (MR_BENCH_PREWARM_MS=0 disables)'),
+                       'prewarm': dict(prewarm, what='untimed launches of the same hot path before the W warm-up steps, so that the timed window does not start on idle clocks (MR_BENCH_PREWARM_LAUNCHES=0 disables)'),
                        'parallelism': f'objects sharded x{world}' + (f', 1 all-gather of 88 B/object x {comm["steps_per_collective"]} step(s) per collective' if (world > 1 and comm) else '')},
             'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          # filled in below: `achieved` / `frac` describe the TIMED REGIME (the kernel instantiation and issue pattern `value` was measured on)

@@ -386,7 +386,17 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // scalar loads: 13.5 us either way — the pixel data is late because 16 MB are asked for at once, not because of the prologue).  Requires fp32 head output,
 // h*w % 4 == 0, no coord_2d map (the launcher falls back to the scalar kernel otherwise).
 template <int THREADS, int TRIPS>
-__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj) {
+__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj
+#ifdef MR_K2_EXPERIMENT
+    , unsigned long long *stamps
+#endif
+    ) {
+#ifdef MR_K2_EXPERIMENT
+#define K2_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((long long)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+    K2_STAMP(0);
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
     // one workgroup per object: the object index is wave-uniform, so its parameters (label, flip, dims, RoI, coder constants — two
     // dependent rounds of loads) are fetched through the scalar cache once per wave instead of once per lane.  A thread takes up
     // to TRIPS pixel quads (q = t, t + THREADS, ...): all their loads are issued before the first quad is decoded, so the
@@ -406,6 +416,7 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
     }
     const float *ap = (const float *)a.all_pred;
     const double rc_sd_sq = 1.0 / (double)a.sd_sq, rc_std_scale = 1.0 / (double)a.std_scale;      // div_by_uniform
+    K2_STAMP(1);
     for (int q0 = threadIdx.x; q0 < quads_per_obj; q0 += THREADS * TRIPS) {
         float4 in[TRIPS][5];
 #pragma unroll
@@ -418,6 +429,10 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 for (int k = 0; k < 2; ++k) in[t][3 + k] = *(const float4 *)(ap + o.base + (long long)(o.ch_ls + k) * hw + 4 * q);
             }
         }
+#ifdef MR_K2_EXPERIMENT
+        K2_STAMP(2);
+        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K2_STAMP(3); }
+#endif
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
             const int q = q0 + t * THREADS;
@@ -449,9 +464,15 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 st4(a.istd + ((long long)b * 2 + k) * hw + p0, out[2 + k]);
             }
 #pragma unroll
+            K2_STAMP(4);
             for (int k = 0; k < 3; ++k) st4(a.c3d + ((long long)b * 3 + k) * hw + p0, out[4 + k]);
         }
     }
+#ifdef MR_K2_EXPERIMENT
+    K2_STAMP(5);
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K2_STAMP(6); }
+#endif
+#undef K2_STAMP
 }
 
 // numpy's pairwise summation tree for a length-P contiguous float32 reduction, built on the host:
@@ -1232,9 +1253,27 @@ int mr_noc_decode_batched(
         // 256 threads x one quad measured best (13.1 us per 1024 x 28x28 batch; 128 x 2 quads 14.2, 64 x 4 quads 25.5: the kernel wants threads, not trips);
         // a persistent, three-stage software-pipelined form (loads of the next quad in flight during the arithmetic; bit-identical outputs) is NOT faster:
         // 13.0 - 14.9 us against 12.5 in the same session (tools/ubench/k2_pipelined_experiment.inc, profiles/r04_k2_pipelined_experiment.txt)
+#ifdef MR_K2_EXPERIMENT
+        {
+            static const int lds = getenv("MR_K2_LDS") ? atoi(getenv("MR_K2_LDS")) : 0;       // dynamic LDS nobody uses: caps the workgroups resident per CU
+            static const int thr = getenv("MR_K2_THREADS") ? atoi(getenv("MR_K2_THREADS")) : 256;
+            if (lds > 48 * 1024) {
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                             (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                             (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+            }
+            if (thr == 64) hipLaunchKernelGGL((noc_decode_kernel_x4<64, 4>), dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
+            else if (thr == 128) hipLaunchKernelGGL((noc_decode_kernel_x4<128, 2>), dim3((unsigned)B), dim3(128), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
+            else hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
+            HIP_TRY(hipGetLastError());
+            return MR_OK;
+        }
+#else
         hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4);
         HIP_TRY(hipGetLastError());
         return MR_OK;
+#endif
     }
     const long long blocks = (long long)((hw + 255) / 256) * B;
     if (blocks > 0x7fffffffLL) return MR_ERR_UNSUPPORTED;

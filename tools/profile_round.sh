@@ -24,7 +24,7 @@ prof() {   # prof <subdir> <counters or ""> -- <command...>
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 SQ2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE GRBM_COUNT"
 if [[ " $PARTS " == *" stream1 "* ]]; then
-    B="env MR_BENCH_PREWARM_MS=0 python $R/bench.py --steps 96 --warmup 12 --no-cpu-baseline --no-secondary --in-flight 1"
+    B="env MR_BENCH_PREWARM_LAUNCHES=0 python $R/bench.py --steps 96 --warmup 12 --no-cpu-baseline --no-secondary --in-flight 1"
     prof trace1 "" -- $B
     prof pmc1_fetch "FETCH_SIZE" -- $B
     prof pmc1_write "WRITE_SIZE" -- $B
@@ -36,7 +36,7 @@ if [[ " $PARTS " == *" inflight "* ]]; then
     prof trace4 "" -- python $R/bench.py --steps 96 --warmup 12 --no-cpu-baseline --no-secondary --in-flight 4
     # ... and its counters from isolated launches of the SAME kernel (--waves 2 on one stream): counter collection serialises
     # kernels anyway (under it the pipeline's overlap self-test finds no two streams that run side by side and falls back to depth 1)
-    B="env MR_BENCH_PREWARM_MS=0 python $R/bench.py --steps 96 --warmup 12 --no-cpu-baseline --no-secondary --in-flight 1 --waves 2"
+    B="env MR_BENCH_PREWARM_LAUNCHES=0 python $R/bench.py --steps 96 --warmup 12 --no-cpu-baseline --no-secondary --in-flight 1 --waves 2"
     prof pmc4_fetch "FETCH_SIZE" -- $B
     prof pmc4_write "WRITE_SIZE" -- $B
     prof pmc4_sq "$SQ1" -- $B
