@@ -374,10 +374,15 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // seven 16-byte stores of the decoded channels (the scalar kernel above moves 4 bytes per lane and instruction and leaves the last
 // of an object's ceil(784/256) = 4 blocks 94 % idle: 15.1 us per 1024 x 28x28 batch = 32 % of the HBM roofline).  One workgroup per
 // object (grid = B).  Same per-pixel arithmetic (two pixels per packed instruction), hence bit-identical outputs.  Timeline of a
-// 1024-object launch (100 MHz stamps inside the kernel): workgroups start within 0.4 us, their loads land after 3.3 - 4.2 us, the
-// arithmetic takes 3.6 - 5.9 us, the stores are acknowledged 0.3 us later: 10.0 us from the first wave to the last; rocprofv3
-// reports 13.1 us for the dispatch (its ~3 us floor for any kernel included).  The phases do not overlap because every workgroup
-// is in the same phase at the same time; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us, div_by_uniform (16 IEEE divisions
+// 1024-object launch (100 MHz stamps of every wave, -DMR_K2_EXPERIMENT build, tools/gpu_k2_timeline.py, profiles/r04_k2_timeline.txt):
+// waves start within 0.7 us; the object's parameters are there 2.0 us after a wave's start (three dependent rounds of loads: kernel
+// arguments, label / flip / RoI / dimensions, the label's class rows), the pixel loads are issued 0.9 us later and land after another
+// 0.5 us — the pixel data is NOT what is late —, the arithmetic takes 3.1 us per wave (2.2 - 4.1), the stores are acknowledged 0.4 us
+// later: 10.2 us from the first wave's start to the last wave's end; rocprofv3 reports 12.4 - 13.3 us for the dispatch.  Neither
+// fewer waves (a grouped form, several objects per workgroup with the lanes numbered through their quads: 3 328 instead of 4 096
+// waves, -15 % VALU instructions, class rows through LDS, pixel loads issued right behind label and flip; bit-identical) nor a cap on
+// the resident workgroups changes the launch time (12.2 - 13.2 us; tools/ubench/k2_grouped_experiment.patch): the launch is neither
+// issue- nor bandwidth-bound, it is the sum of its per-wave latencies; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us, div_by_uniform (16 IEEE divisions
 // per lane -> 16 float64 products) another 0.3 - 0.5 us (12.9 us); running the exp / log sequences without their range tests and selects
 // (-80 VALU instructions per wave; a wave redoes its pixels when a lane meets a special input) nothing (12.9 us), and neither did a four-pixel
 // vector form whose Horner chains interleave (s_nop between dependent packed operations 194 -> 38; 12.9 - 13.8 us); starting the waves that share
@@ -463,8 +468,8 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 st4(a.c2d + ((long long)b * 2 + k) * hw + p0, out[k]);
                 st4(a.istd + ((long long)b * 2 + k) * hw + p0, out[2 + k]);
             }
-#pragma unroll
             K2_STAMP(4);
+#pragma unroll
             for (int k = 0; k < 3; ++k) st4(a.c3d + ((long long)b * 3 + k) * hw + p0, out[4 + k]);
         }
     }
