@@ -13,7 +13,7 @@ NB, S = 12, 24
 print('library:', os.environ.get('MR_PNP_SO', '(default)'))
 for hw in [int(x) for x in os.environ.get("TILES", "28,24,22,20").split(",")]:
     batches = [[dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, hw=hw, seed=1234 + 7919 * i), planar=True)] for i in range(NB)]
-    ls = [[PnPLaunch(*b[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=b[6], inlier_opt_only=True, flags=(2 << 8) | int(os.environ.get("EXTRA_FLAGS", "0"), 0)) for b in batches] for _ in range(S)]
+    ls = [[PnPLaunch(*b[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=b[6], inlier_opt_only=True, flags=(int(os.environ.get("WAVES", "2")) << 8) | int(os.environ.get("EXTRA_FLAGS", "0"), 0)) for b in batches] for _ in range(S)]
     pipe = PnPPipeline(dev, depth=4)
     for steps in (20, 240):
         res = []
