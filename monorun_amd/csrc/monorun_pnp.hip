@@ -462,7 +462,10 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 for (int k = 0; k < 3; ++k) { out[4 + k][j] = c3[k].x; out[4 + k][j + 1] = c3[k].y; }
             }
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            auto st4 = [](float *dst, const float (&v)[4]) { *(f32x4 *)dst = f32x4{ v[0], v[1], v[2], v[3] }; };     // (non-temporal stores: no difference, measured)
+            // NON-TEMPORAL stores (`global_store_dwordx4 ... nt`): the 22 MB a launch writes are not kept in L2, so the write-back at the end
+            // of the dispatch has little left to do: 10.2 - 11.3 us per launch against 12.1 - 12.7 us with plain stores (300 launches each way,
+            // alternating; `sc0 sc1` write-through stores give the same, non-temporal LOADS nothing: profiles/r04_k2_store_policy.txt)
+            auto st4 = [](float *dst, const float (&v)[4]) { __builtin_nontemporal_store(f32x4{ v[0], v[1], v[2], v[3] }, (f32x4 *)dst); };
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 st4(a.c2d + ((long long)b * 2 + k) * hw + p0, out[k]);

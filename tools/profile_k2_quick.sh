@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/k2_trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k2_trace -o t -- env WHICH=k2 REPS=60 MR_PNP_SO=${MR_PNP_SO:-} python $R/tools/gpu_noc_path.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k2_trace -o t -- env WHICH=k2 REPS=${REPS:-60} MR_PNP_SO=${MR_PNP_SO:-} python $R/tools/gpu_noc_path.py > /dev/null 2>&1
 python - <<'P'
 import csv, glob, os
 f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/k2_trace/**/t_kernel_stats.csv', recursive=True)[0]
