@@ -422,6 +422,35 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
     const float *ap = (const float *)a.all_pred;
     const double rc_sd_sq = 1.0 / (double)a.sd_sq, rc_std_scale = 1.0 / (double)a.std_scale;      // div_by_uniform
     K2_STAMP(1);
+    if constexpr (TRIPS == 1) {
+        // The last wave of an object owns only the quads left over (28x28: 4 of 196) and would still issue the whole two-pairs-per-lane
+        // instruction stream for them.  With at most 32 quads left it works on PAIRS instead: lane l takes pixels (2l, 2l + 1) of the
+        // wave's range — one pass through the same packed arithmetic, half the instructions, 8-byte loads and stores.
+        const int w0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 64;      // first quad of this wave
+        const int nq = quads_per_obj - w0;
+        if (nq > 0 && nq <= 32) {
+            const int l = threadIdx.x & 63;
+            if (l < 2 * nq) {
+                const int p0 = 4 * w0 + 2 * l;
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+                f32x2 noc[3], ls[2], c2[2], w2[2], c3[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const float2 v = *(const float2 *)(ap + o.base + (long long)(o.ch_noc + k) * hw + p0); noc[k].x = v.x; noc[k].y = v.y; }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { const float2 v = *(const float2 *)(ap + o.base + (long long)(o.ch_ls + k) * hw + p0); ls[k].x = v.x; ls[k].y = v.y; }
+                decode_pixel_pair(a, o, p0, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale);
+                auto st2 = [](float *dst, f32x2 v) { __builtin_nontemporal_store(f32x2v{ v.x, v.y }, (f32x2v *)dst); };
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    st2(a.c2d + ((long long)b * 2 + k) * hw + p0, c2[k]);
+                    st2(a.istd + ((long long)b * 2 + k) * hw + p0, w2[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st2(a.c3d + ((long long)b * 3 + k) * hw + p0, c3[k]);
+            }
+            return;
+        }
+    }
     for (int q0 = threadIdx.x; q0 < quads_per_obj; q0 += THREADS * TRIPS) {
         float4 in[TRIPS][5];
 #pragma unroll
