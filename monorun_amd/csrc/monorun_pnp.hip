@@ -281,7 +281,10 @@ __global__ void __launch_bounds__(256) noc_decode_kernel(const DecodeArgs a) {
 // a PAIR of pixels (v_pk_mul_f32 / v_pk_add_f32: one instruction, two IEEE float32 results, each bit-identical to the scalar
 // operation), the special cases become selects after the common path.  mr_expf / mr_logf / decode_pixel_vals stay the definition.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 mr_expf2(f32x2 x) {
+// CHECKED = false: the common path only — the caller is told (`special`) when an argument falls into a special case and redoes the
+// work with the checked form; on ordinary inputs this drops the compares and selects (~ 10 % of the vector kernel's instructions).
+template <bool CHECKED = true>
+__device__ __forceinline__ f32x2 mr_expf2(f32x2 x, bool *special = nullptr) {
 #pragma clang fp contract(off)
     f32x2 kf;
     kf.x = rintf(x.x * 1.44269504088896341f); kf.y = rintf(x.y * 1.44269504088896341f);
@@ -297,11 +300,18 @@ __device__ __forceinline__ f32x2 mr_expf2(f32x2 x) {
     y = y + 1.0f;
     f32x2 o;
     o.x = ldexpf(y.x, (int)kf.x); o.y = ldexpf(y.y, (int)kf.y);
-    o.x = x.x > 88.72283935546875f ? __int_as_float(0x7f800000) : (x.x < -103.0f ? 0.0f : o.x);
-    o.y = x.y > 88.72283935546875f ? __int_as_float(0x7f800000) : (x.y < -103.0f ? 0.0f : o.y);
+    if constexpr (CHECKED) {
+        o.x = x.x > 88.72283935546875f ? __int_as_float(0x7f800000) : (x.x < -103.0f ? 0.0f : o.x);
+        o.y = x.y > 88.72283935546875f ? __int_as_float(0x7f800000) : (x.y < -103.0f ? 0.0f : o.y);
+    } else {
+        // conservative: |x + 7.14| > 95.8 holds for every x > 88.72283935546875 and every x < -103 (and for a sliver inside the range: a
+        // false alarm only costs the redo); a NaN is not special — it goes through the same arithmetic in the checked form
+        *special = *special || (fabsf(x.x + 7.14f) > 95.8f) || (fabsf(x.y + 7.14f) > 95.8f);
+    }
     return o;
 }
-__device__ __forceinline__ f32x2 mr_logf2(f32x2 x) {
+template <bool CHECKED = true>
+__device__ __forceinline__ f32x2 mr_logf2(f32x2 x, bool *special = nullptr) {
 #pragma clang fp contract(off)
     int e0, e1;
     f32x2 m;
@@ -327,8 +337,12 @@ __device__ __forceinline__ f32x2 mr_logf2(f32x2 x) {
     const f32x2 zz = m + y;
     f32x2 o = zz + 0.693359375f * fe;
     const float inf = __int_as_float(0x7f800000), nan = __int_as_float(0x7fc00000);
-    o.x = !(x.x > 0.0f) ? (x.x == 0.0f ? -inf : nan) : (x.x == inf ? x.x : o.x);
-    o.y = !(x.y > 0.0f) ? (x.y == 0.0f ? -inf : nan) : (x.y == inf ? x.y : o.y);
+    if constexpr (CHECKED) {
+        o.x = !(x.x > 0.0f) ? (x.x == 0.0f ? -inf : nan) : (x.x == inf ? x.x : o.x);
+        o.y = !(x.y > 0.0f) ? (x.y == 0.0f ? -inf : nan) : (x.y == inf ? x.y : o.y);
+    } else {
+        *special = *special || !(x.x > 0.0f) || !(x.y > 0.0f) || x.x == inf || x.y == inf;      // zero, negative, NaN, +inf
+    }
     return o;
 }
 // pixels p and p + 1 of one object row-major (p even, same row: w is even whenever h * w % 4 == 0 ... not required: px / py per pixel)
@@ -339,8 +353,12 @@ __device__ __forceinline__ f32x2 mr_logf2(f32x2 x) {
 // NaNs, c = 0, overflow and float32 denormals go through the float64 product and the conversion unchanged.  rc = 1.0 / (double)c.
 __device__ __forceinline__ float div_by_uniform(float x, double rc) { return (float)((double)x * rc); }
 
+// w_magic = floor((2^32 - 1) / w) + 1: p / w == __umulhi(p, w_magic) for p, w < 2^16 (the error of the product is p (w_magic w - 2^32)
+// / (w 2^32) < p / 2^32 < 1 / w) — the two integer divisions per pixel pair were ~ 12 % of the kernel's instructions
+template <bool CHECKED = true>
 __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const DecodeObj &o, int p, const f32x2 (&nocv)[3], const f32x2 (&lsv)[2],
-                                                  f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3], double rc_sd_sq, double rc_std_scale) {
+                                                  f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3], double rc_sd_sq, double rc_std_scale, unsigned w_magic,
+                                                  bool *special = nullptr) {
 #pragma clang fp contract(off)
     f32x2 xv[3];
 #pragma unroll
@@ -355,15 +373,17 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
         const f32x2 ls = lsv[k];
         f32x2 lspx;
         if (a.has_var) {
-            const f32x2 num = v2[k] * a.k_epi + mr_expf2(2.0f * ls) * a.k_sd2;
+            const f32x2 num = v2[k] * a.k_epi + mr_expf2<CHECKED>(2.0f * ls, special) * a.k_sd2;
             f32x2 q;
             q.x = div_by_uniform(num.x, rc_sd_sq); q.y = div_by_uniform(num.y, rc_sd_sq);
-            lspx = 0.5f * mr_logf2(q);
+            lspx = 0.5f * mr_logf2<CHECKED>(q, special);
         } else lspx = ls + 0.0f;                                  // log(sd / sd)
-        const f32x2 ex = mr_expf2(-lspx);
+        const f32x2 ex = mr_expf2<CHECKED>(-lspx, special);
         istd[k].x = div_by_uniform(ex.x, rc_std_scale); istd[k].y = div_by_uniform(ex.y, rc_std_scale);
     }
-    const int py0 = p / a.w, px0 = p - py0 * a.w, py1 = (p + 1) / a.w, px1 = (p + 1) - py1 * a.w;
+    const int py0 = (int)__umulhi((unsigned)p, w_magic), px0 = p - py0 * a.w;
+    const bool wrap = px0 + 1 == a.w;                             // pixel p + 1 starts the next row
+    const int py1 = wrap ? py0 + 1 : py0, px1 = wrap ? 0 : px0 + 1;
     f32x2 fx, fy;
     fx.x = (float)px0; fx.y = (float)px1; fy.x = (float)py0; fy.y = (float)py1;
     c2d[0] = (o.x1 - 0.5f) + (fx + 0.5f) * o.su;
@@ -391,7 +411,7 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // scalar loads: 13.5 us either way — the pixel data is late because 16 MB are asked for at once, not because of the prologue).  Requires fp32 head output,
 // h*w % 4 == 0, no coord_2d map (the launcher falls back to the scalar kernel otherwise).
 template <int THREADS, int TRIPS>
-__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj
+__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj, unsigned w_magic
 #ifdef MR_K2_EXPERIMENT
     , unsigned long long *stamps
 #endif
@@ -438,7 +458,9 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
                 for (int k = 0; k < 3; ++k) { const float2 v = *(const float2 *)(ap + o.base + (long long)(o.ch_noc + k) * hw + p0); noc[k].x = v.x; noc[k].y = v.y; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) { const float2 v = *(const float2 *)(ap + o.base + (long long)(o.ch_ls + k) * hw + p0); ls[k].x = v.x; ls[k].y = v.y; }
-                decode_pixel_pair(a, o, p0, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale);
+                bool special = false;
+                decode_pixel_pair<false>(a, o, p0, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale, w_magic, &special);
+                if (special) decode_pixel_pair<true>(a, o, p0, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale, w_magic);
                 auto st2 = [](float *dst, f32x2 v) { __builtin_nontemporal_store(f32x2v{ v.x, v.y }, (f32x2v *)dst); };
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -473,23 +495,31 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
             if (q >= quads_per_obj) break;
             const int p0 = 4 * q;
             float out[7][4];
+            // pixel pairs (p0, p0 + 1), (p0 + 2, p0 + 3): packed float32 arithmetic.  First the common path of the specified exp / log
+            // sequences (no range tests, no selects); a lane that met a special input redoes its quad with the checked forms.
+            auto quad = [&](auto checked, bool *special) {
+                constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {                  // pixel pairs (p0, p0 + 1), (p0 + 2, p0 + 3): packed float32 arithmetic
-                f32x2 noc[3], ls[2], c2[2], w2[2], c3[3];
+                for (int j = 0; j < 4; j += 2) {
+                    f32x2 noc[3], ls[2], c2[2], w2[2], c3[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { noc[k].x = ((const float *)&in[t][k])[j]; noc[k].y = ((const float *)&in[t][k])[j + 1]; }
+                    for (int k = 0; k < 3; ++k) { noc[k].x = ((const float *)&in[t][k])[j]; noc[k].y = ((const float *)&in[t][k])[j + 1]; }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { ls[k].x = ((const float *)&in[t][3 + k])[j]; ls[k].y = ((const float *)&in[t][3 + k])[j + 1]; }
+                    for (int k = 0; k < 2; ++k) { ls[k].x = ((const float *)&in[t][3 + k])[j]; ls[k].y = ((const float *)&in[t][3 + k])[j + 1]; }
 #ifdef MR_K2_COPY_ONLY      // ubench: the kernel's memory traffic without its arithmetic (tools/profile_k2_quick.sh on a variant build)
-                c2[0] = noc[0]; c2[1] = noc[1]; w2[0] = ls[0]; w2[1] = ls[1]; c3[0] = noc[2]; c3[1] = noc[0] + ls[0]; c3[2] = noc[1] + ls[1];
+                    c2[0] = noc[0]; c2[1] = noc[1]; w2[0] = ls[0]; w2[1] = ls[1]; c3[0] = noc[2]; c3[1] = noc[0] + ls[0]; c3[2] = noc[1] + ls[1];
 #else
-                decode_pixel_pair(a, o, p0 + j, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale);
+                    decode_pixel_pair<CHECKED>(a, o, p0 + j, noc, ls, c2, w2, c3, rc_sd_sq, rc_std_scale, w_magic, special);
 #endif
-                out[0][j] = c2[0].x; out[0][j + 1] = c2[0].y; out[1][j] = c2[1].x; out[1][j + 1] = c2[1].y;
-                out[2][j] = w2[0].x; out[2][j + 1] = w2[0].y; out[3][j] = w2[1].x; out[3][j + 1] = w2[1].y;
+                    out[0][j] = c2[0].x; out[0][j + 1] = c2[0].y; out[1][j] = c2[1].x; out[1][j + 1] = c2[1].y;
+                    out[2][j] = w2[0].x; out[2][j + 1] = w2[0].y; out[3][j] = w2[1].x; out[3][j + 1] = w2[1].y;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { out[4 + k][j] = c3[k].x; out[4 + k][j + 1] = c3[k].y; }
-            }
+                    for (int k = 0; k < 3; ++k) { out[4 + k][j] = c3[k].x; out[4 + k][j + 1] = c3[k].y; }
+                }
+            };
+            bool special = false;
+            quad(std::false_type{}, &special);
+            if (special) quad(std::true_type{}, nullptr);
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             // NON-TEMPORAL stores (`global_store_dwordx4 ... nt`): the 22 MB a launch writes are not kept in L2, so the write-back at the end
             // of the dispatch has little left to do: 10.2 - 11.3 us per launch against 12.1 - 12.7 us with plain stores (300 launches each way,
@@ -1284,7 +1314,8 @@ int mr_noc_decode_batched(
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     a.map2d = coord_2d_map; a.map_h = map_h; a.map_w = map_w;
     const int hw = h * w;
-    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) &&
+    const unsigned w_magic = 0xFFFFFFFFu / (unsigned)w + 1u;      // p / w by multiplication (decode_pixel_pair); exact for p, w < 65536
+    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) && hw < 65536 && w > 1 &&
                     ((((uintptr_t)all_pred | (uintptr_t)coords_2d | (uintptr_t)coords_2d_istd | (uintptr_t)coords_3d) & 15) == 0);
     if (x4) {
         // 256 threads x one quad measured best (13.1 us per 1024 x 28x28 batch; 128 x 2 quads 14.2, 64 x 4 quads 25.5: the kernel wants threads, not trips);
@@ -1300,14 +1331,14 @@ int mr_noc_decode_batched(
                              (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                              (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
             }
-            if (thr == 64) hipLaunchKernelGGL((noc_decode_kernel_x4<64, 4>), dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
-            else if (thr == 128) hipLaunchKernelGGL((noc_decode_kernel_x4<128, 2>), dim3((unsigned)B), dim3(128), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
-            else hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
+            if (thr == 64) hipLaunchKernelGGL((noc_decode_kernel_x4<64, 4>), dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
+            else if (thr == 128) hipLaunchKernelGGL((noc_decode_kernel_x4<128, 2>), dim3((unsigned)B), dim3(128), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
+            else hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
             HIP_TRY(hipGetLastError());
             return MR_OK;
         }
 #else
-        hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4);
+        hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4, w_magic);
         HIP_TRY(hipGetLastError());
         return MR_OK;
 #endif

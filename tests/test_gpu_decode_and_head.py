@@ -536,3 +536,28 @@ def test_head_built_with_the_reference_initialiser_is_honoured_everywhere(dev, o
     assert np.abs(rr[2] - ref[2])[ref[0]].max() <= 1e-4 and np.abs(np.angle(np.exp(1j * (rr[1] - ref[1]))))[ref[0]].max() <= 1e-4
     with pytest.raises(ValueError):
         u2d_pnp_cpu(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True, initialiser='opencv')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w', [(6, 6), (10, 6), (4, 7), (12, 5), (2, 2), (28, 28), (14, 30)])
+def test_k2_vector_kernel_on_maps_whose_rows_do_not_hold_whole_quads(dev, orc, h, w):
+    """h * w % 4 == 0 takes the vector kernel (four pixels per lane; the last wave of an object in pairs) also when w % 4 != 0: quads and
+    pairs then straddle rows, and the pixel grid (row = p / w by multiplication) must still be the oracle's."""
+    from monorun_amd.pose_head import noc_decode
+    rng = np.random.default_rng(100 * h + w)
+    B, C = 37, 3
+    pred = rng.normal(0, 1, (B, 2 * C * 5, h, w)).astype(np.float32)
+    labels = rng.integers(0, C, B); flip = rng.integers(0, 2, B).astype(bool)
+    dim = rng.normal(0, 1, (B, 3)).astype(np.float32); dim_var = (0.01 * rng.random((B, 3)) + 1e-4).astype(np.float32)
+    rois = np.stack([rng.uniform(0, 900, B), rng.uniform(0, 200, B)], 1)
+    rois = np.concatenate([rois, rois + rng.uniform(20, 200, (B, 2))], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    dec = noc_decode(t(pred), t(labels), t(flip), t(dim), t(dim_var), t(rois))
+    torch.cuda.synchronize()
+    assert np.array_equal(dec['coords_2d'].cpu().numpy(), orc.roi_grid(rois, h, w))
+    n_noc, n_ls, _ = orc.slice_pred(pred, labels, flip)
+    d_, dv_ = orc.dim_decode(dim, dim_var, labels)
+    c3d_ref, var_ref = orc.noc_decode(n_noc, d_, dv_)
+    assert np.array_equal(dec['coords_3d'].cpu().numpy(), c3d_ref)
+    ls_spec = orc.decode_logstd(n_ls, var_ref, exp=orc.spec_expf, log=orc.spec_logf)
+    assert np.array_equal(dec['coords_2d_istd'].cpu().numpy(), orc.spec_expf(-ls_spec) / np.float32(10))
