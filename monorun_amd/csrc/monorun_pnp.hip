@@ -53,6 +53,7 @@ struct DecodeArgs {
     float k_epi, k_sd2, sd_sq, std_scale, ratio; int has_var;
     float *c2d, *istd, *c3d, *dims, *dims_var, *thr;
     const float *map2d; int map_h, map_w;      // optional coord_2d map (2, H, W): exact RoIAlign sampling instead of the analytic grid
+    unsigned w_magic;                          // floor((2^32 - 1) / w) + 1 (0 when w == 1 or h * w >= 65536): row index p / w == __umulhi(p, w_magic), decode_pixel_pair
 };
 
 // RoIAlign forward, average pooling (mmcv.ops.roi_align: the published Detectron/mmcv algorithm, mmcv 1.2.1
@@ -355,10 +356,11 @@ __device__ __forceinline__ float div_by_uniform(float x, double rc) { return (fl
 
 // w_magic = floor((2^32 - 1) / w) + 1: p / w == __umulhi(p, w_magic) for p, w < 2^16 (the error of the product is p (w_magic w - 2^32)
 // / (w 2^32) < p / 2^32 < 1 / w) — the two integer divisions per pixel pair were ~ 12 % of the kernel's instructions
-template <bool CHECKED = true>
+// The two pixels are p and p + 1 (the vector decode kernel), or p and pb (the fused kernel's load stage: a lane's pixels are a stride apart).
+template <bool CHECKED = true, bool ADJACENT = true>
 __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const DecodeObj &o, int p, const f32x2 (&nocv)[3], const f32x2 (&lsv)[2],
                                                   f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3], double rc_sd_sq, double rc_std_scale, unsigned w_magic,
-                                                  bool *special = nullptr) {
+                                                  bool *special = nullptr, int pb = 0) {
 #pragma clang fp contract(off)
     f32x2 xv[3];
 #pragma unroll
@@ -382,8 +384,11 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
         istd[k].x = div_by_uniform(ex.x, rc_std_scale); istd[k].y = div_by_uniform(ex.y, rc_std_scale);
     }
     const int py0 = (int)__umulhi((unsigned)p, w_magic), px0 = p - py0 * a.w;
-    const bool wrap = px0 + 1 == a.w;                             // pixel p + 1 starts the next row
-    const int py1 = wrap ? py0 + 1 : py0, px1 = wrap ? 0 : px0 + 1;
+    int py1, px1;
+    if constexpr (ADJACENT) {
+        const bool wrap = px0 + 1 == a.w;                         // pixel p + 1 starts the next row
+        py1 = wrap ? py0 + 1 : py0; px1 = wrap ? 0 : px0 + 1;
+    } else { py1 = (int)__umulhi((unsigned)pb, w_magic); px1 = pb - py1 * a.w; }
     f32x2 fx, fy;
     fx.x = (float)px0; fx.y = (float)px1; fy.x = (float)py0; fy.y = (float)py1;
     c2d[0] = (o.x1 - 0.5f) + (fx + 0.5f) * o.su;
@@ -1293,6 +1298,7 @@ static int fill_decode_args(DecodeArgs &a, const void *all_pred, int pred_dtype,
     const float sdf = (float)proj_scaling_denominator;
     a.sd_sq = sdf * sdf;
     a.std_scale = std_scale; a.ratio = ransac_thres_ratio; a.has_var = dim_var != nullptr;
+    a.w_magic = (w > 1 && (long long)h * w < 65536) ? 0xFFFFFFFFu / (unsigned)w + 1u : 0u;
     return MR_OK;
 }
 
@@ -1314,8 +1320,8 @@ int mr_noc_decode_batched(
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     a.map2d = coord_2d_map; a.map_h = map_h; a.map_w = map_w;
     const int hw = h * w;
-    const unsigned w_magic = 0xFFFFFFFFu / (unsigned)w + 1u;      // p / w by multiplication (decode_pixel_pair); exact for p, w < 65536
-    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) && hw < 65536 && w > 1 &&
+    const unsigned w_magic = a.w_magic;                           // p / w by multiplication (decode_pixel_pair); exact for p, w < 65536
+    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) && w_magic != 0u &&
                     ((((uintptr_t)all_pred | (uintptr_t)coords_2d | (uintptr_t)coords_2d_istd | (uintptr_t)coords_3d) & 15) == 0);
     if (x4) {
         // 256 threads x one quad measured best (13.1 us per 1024 x 28x28 batch; 128 x 2 quads 14.2, 64 x 4 quads 25.5: the kernel wants threads, not trips);
@@ -1328,8 +1334,8 @@ int mr_noc_decode_batched(
             if (lds > 48 * 1024) {
                 static bool once = false;
                 if (!once) { (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                             (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                             (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+                             (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                             (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
             }
             if (thr == 64) hipLaunchKernelGGL((noc_decode_kernel_x4<64, 4>), dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
             else if (thr == 128) hipLaunchKernelGGL((noc_decode_kernel_x4<128, 2>), dim3((unsigned)B), dim3(128), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
