@@ -396,25 +396,21 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 }
 
 // K2, vector form: one thread per FOUR consecutive RoI pixels of one object — five 16-byte loads of the selected head channels,
-// seven 16-byte stores of the decoded channels (the scalar kernel above moves 4 bytes per lane and instruction and leaves the last
-// of an object's ceil(784/256) = 4 blocks 94 % idle: 15.1 us per 1024 x 28x28 batch = 32 % of the HBM roofline).  One workgroup per
-// object (grid = B).  Same per-pixel arithmetic (two pixels per packed instruction), hence bit-identical outputs.  Timeline of a
-// 1024-object launch (100 MHz stamps of every wave, -DMR_K2_EXPERIMENT build, tools/gpu_k2_timeline.py, profiles/r04_k2_timeline.txt):
-// waves start within 0.7 us; the object's parameters are there 2.0 us after a wave's start (three dependent rounds of loads: kernel
-// arguments, label / flip / RoI / dimensions, the label's class rows), the pixel loads are issued 0.9 us later and land after another
-// 0.5 us — the pixel data is NOT what is late —, the arithmetic takes 3.1 us per wave (2.2 - 4.1), the stores are acknowledged 0.4 us
-// later: 10.2 us from the first wave's start to the last wave's end; rocprofv3 reports 12.4 - 13.3 us for the dispatch.  Neither
-// fewer waves (a grouped form, several objects per workgroup with the lanes numbered through their quads: 3 328 instead of 4 096
-// waves, -15 % VALU instructions, class rows through LDS, pixel loads issued right behind label and flip; bit-identical) nor a cap on
-// the resident workgroups changes the launch time (12.2 - 13.2 us; tools/ubench/k2_grouped_experiment.patch): the launch is neither
-// issue- nor bandwidth-bound, it is the sum of its per-wave latencies; packed arithmetic (-24 % executed VALU instructions) bought 0.5 us, div_by_uniform (16 IEEE divisions
-// per lane -> 16 float64 products) another 0.3 - 0.5 us (12.9 us); running the exp / log sequences without their range tests and selects
-// (-80 VALU instructions per wave; a wave redoes its pixels when a lane meets a special input) nothing (12.9 us), and neither did a four-pixel
-// vector form whose Horner chains interleave (s_nop between dependent packed operations 194 -> 38; 12.9 - 13.8 us); starting the waves that share
-// a SIMD 0.2 - 0.8 us apart (s_sleep by hardware wave slot) changed nothing (13.5 - 14.4 us, inside the run-to-run spread); nor did issuing
-// the pixel loads right behind label + flip, ahead of the object's other parameters (decode_object compiles to five dependent rounds of
-// scalar loads: 13.5 us either way — the pixel data is late because 16 MB are asked for at once, not because of the prologue).  Requires fp32 head output,
-// h*w % 4 == 0, no coord_2d map (the launcher falls back to the scalar kernel otherwise).
+// seven 16-byte NON-TEMPORAL stores of the decoded channels.  One workgroup per object (grid = B).  Same per-pixel arithmetic as the
+// scalar kernel above (two pixels per packed instruction), hence bit-identical outputs.  What bounds it, as measured (per-wave 100 MHz
+// stamps of a -DMR_K2_EXPERIMENT build, tools/gpu_k2_timeline.py, profiles/r04_k2_timeline.txt, r04_k2_store_policy.txt):
+//   * a wave has its parameters 2.0 us after it starts (three dependent rounds of loads), its pixel loads out 0.9 us later, the data
+//     0.5 us later — the pixel data is NOT what is late —, its arithmetic done after another 3.1 us; waves start within 0.7 us;
+//   * with plain stores the profiler counted 2 - 3 us more than the last wave's end: the write-back of the 22 MB of outputs from L2 when
+//     the dispatch ends.  Non-temporal stores send them on during the launch (12.1 - 12.7 -> 10.2 - 11.9 us);
+//   * from there the launch is instruction-issue-bound, and cuts of the stream count: the object's last wave on pixel pairs, the row
+//     index by multiplication, the exp / log sequences on their common path first (809 -> 620 VALU instructions per wave; 9.5 - 9.8 us
+//     per launch issued back to back = 0.49 - 0.51 of 8 TB/s, an isolated launch 8.0 us).
+// Measured and not kept (same files; HISTORY.md): a persistent software-pipelined form, 128- and 64-thread workgroups, caps on the
+// resident workgroups, a grouped form (several objects per workgroup, lanes numbered through their quads), non-temporal loads, the class
+// rows fetched ahead of the label, the pixel loads issued ahead of the other parameters, starting the waves of a SIMD apart, Horner
+// chains interleaved across four pixels.  Requires fp32 head output, h * w % 4 == 0 and < 65536, no coord_2d map (the launcher falls
+// back to the scalar kernel otherwise).
 template <int THREADS, int TRIPS>
 __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj, unsigned w_magic
 #ifdef MR_K2_EXPERIMENT
