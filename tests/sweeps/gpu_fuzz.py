@@ -27,7 +27,7 @@ for trial in range(int(os.environ.get('TRIALS', 40))):
     elif mode == 6: thr[sel] = 0.0                                 # zero consensus threshold
     elif mode == 7: x2d[sel] = np.inf
     planar = x2d.strides[1] == 4
-    for wpo in (0, 1, 4):
+    for wpo in (0, 1, 2, 4):
         out = pnp_uncert_device(dv(x2d), dv(istd), dv(x3d), dv(K), dv(ur), dv(vr), 0.5, 0.6, dv(thr), True, flags=(wpo << _lib.MR_WAVES_SHIFT), with_diag=True)
         torch.cuda.synchronize()
         valid, pose = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy()
