@@ -402,8 +402,6 @@ def run(args):
     # never in that state, so MR_BENCH_PREWARM_LAUNCHES (default 2048, ~ 60 ms) launches of the hot path are issued through the same
     # pipeline first; the W warm-up steps of the contract follow as before.
     prewarm_n = int(os.environ.get('MR_BENCH_PREWARM_LAUNCHES', '2048'))
-    if os.environ.get('MR_BENCH_PREWARM_MS') == '0':
-        prewarm_n = 0
     prewarm = {'launches_asked': prewarm_n, 'launches': 0, 'ms': 0.0}
     if prewarm_n > 0:
         # the same K-step window first, as a just-started process sees it (reported beside `value`, never as `value`)

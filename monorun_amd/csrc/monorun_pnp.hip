@@ -357,6 +357,7 @@ __device__ __forceinline__ float div_by_uniform(float x, double rc) { return (fl
 // w_magic = floor((2^32 - 1) / w) + 1: p / w == __umulhi(p, w_magic) for p, w < 2^16 (the error of the product is p (w_magic w - 2^32)
 // / (w 2^32) < p / 2^32 < 1 / w) — the two integer divisions per pixel pair were ~ 12 % of the kernel's instructions
 // The two pixels are p and p + 1 (the vector decode kernel), or p and pb (the fused kernel's load stage: a lane's pixels are a stride apart).
+// CHECKED = false needs `special` (it is written); CHECKED = true ignores it.
 template <bool CHECKED = true, bool ADJACENT = true>
 __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const DecodeObj &o, int p, const f32x2 (&nocv)[3], const f32x2 (&lsv)[2],
                                                   f32x2 (&c2d)[2], f32x2 (&istd)[2], f32x2 (&c3d)[3], double rc_sd_sq, double rc_std_scale, unsigned w_magic,
@@ -412,7 +413,7 @@ __device__ __forceinline__ void decode_pixel_pair(const DecodeArgs &a, const Dec
 // chains interleaved across four pixels.  Requires fp32 head output, h * w % 4 == 0 and < 65536, no coord_2d map (the launcher falls
 // back to the scalar kernel otherwise).
 template <int THREADS, int TRIPS>
-__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj, unsigned w_magic
+__global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs a, int quads_per_obj
 #ifdef MR_K2_EXPERIMENT
     , unsigned long long *stamps
 #endif
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(THREADS) noc_decode_kernel_x4(const DecodeArgs
     // loads of the next and the stores of the previous one.
     const int b = blockIdx.x;
     const int hw = a.h * a.w;
+    const unsigned w_magic = a.w_magic;
     DecodeObj o;
     decode_object(a, b, o);
     if (threadIdx.x == 0) {
@@ -1316,8 +1318,7 @@ int mr_noc_decode_batched(
     a.thr = (ransac_thres_ratio >= 0.f) ? ransac_thr : nullptr;
     a.map2d = coord_2d_map; a.map_h = map_h; a.map_w = map_w;
     const int hw = h * w;
-    const unsigned w_magic = a.w_magic;                           // p / w by multiplication (decode_pixel_pair); exact for p, w < 65536
-    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) && w_magic != 0u &&
+    const bool x4 = pred_dtype == MR_F32 && !coord_2d_map && (hw % 4 == 0) && a.w_magic != 0u &&      // w_magic: p / w by multiplication (decode_pixel_pair)
                     ((((uintptr_t)all_pred | (uintptr_t)coords_2d | (uintptr_t)coords_2d_istd | (uintptr_t)coords_3d) & 15) == 0);
     if (x4) {
         // 256 threads x one quad measured best (13.1 us per 1024 x 28x28 batch; 128 x 2 quads 14.2, 64 x 4 quads 25.5: the kernel wants threads, not trips);
@@ -1333,14 +1334,14 @@ int mr_noc_decode_batched(
                              (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                              (void)hipFuncSetAttribute((const void *)noc_decode_kernel_x4<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
             }
-            if (thr == 64) hipLaunchKernelGGL((noc_decode_kernel_x4<64, 4>), dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
-            else if (thr == 128) hipLaunchKernelGGL((noc_decode_kernel_x4<128, 2>), dim3((unsigned)B), dim3(128), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
-            else hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, a, hw / 4, w_magic, g_stamps);
+            if (thr == 64) hipLaunchKernelGGL((noc_decode_kernel_x4<64, 4>), dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
+            else if (thr == 128) hipLaunchKernelGGL((noc_decode_kernel_x4<128, 2>), dim3((unsigned)B), dim3(128), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
+            else hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, a, hw / 4, g_stamps);
             HIP_TRY(hipGetLastError());
             return MR_OK;
         }
 #else
-        hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4, w_magic);
+        hipLaunchKernelGGL((noc_decode_kernel_x4<256, 1>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a, hw / 4);
         HIP_TRY(hipGetLastError());
         return MR_OK;
 #endif
