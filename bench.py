@@ -876,9 +876,9 @@ def roof_of(nbytes, us):
     return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': nbytes}
 
 
-def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=3):
-    """B = 1024 objects from the RAW NOC-head output (1024 x 30 x 28 x 28 fp32 = 96 MB per batch, 3 distinct resident batches =
-    289 MB > the Infinity Cache) to poses: K2 alone (`noc_decode_kernel`, the one HBM-bound kernel of the path), K2 + PnP as two
+def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=4):
+    """B = 1024 objects from the RAW NOC-head output (1024 x 30 x 28 x 28 fp32 = 96 MB per batch, 4 distinct resident batches =
+    385 MB > the Infinity Cache; four = the depth of the pipeline the headline runs with) to poses: K2 alone (`noc_decode_kernel`, the one HBM-bound kernel of the path), K2 + PnP as two
     launches, and the fused one-launch kernel; each with its algorithmic bytes against the 8 TB/s HBM roofline."""
     from monorun_amd.pose_head import NocDecodeLaunch, PoseFromHeadLaunch, UncertPropPnPOptimizer, _planar_view, _clip_ranges
     head = UncertPropPnPOptimizer().to(dev)
