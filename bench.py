@@ -408,8 +408,10 @@ def run(args):
         cold = Loop(L, G_MAIN).timed(args.steps, args.warmup)
         prewarm['window_before'] = {'steps': args.steps, 'warmup': args.warmup, 'value': B_PER_GPU * world * args.steps / cold, 'unit': 'solves/s',
                                     'what': 'the timed window as measured BEFORE the pre-conditioning (idle clocks), same loop, same steps'}
-        # a FIXED number of launches (every rank does the same; no collective in here), through the pipeline of the timed loop
+        # at most prewarm_n launches and about 0.1 s of them (a stress-shape launch lasts ~ 1 ms), no collective in here, through the
+        # pipeline of the timed loop
         pp = pipe_of(L_ASKED)
+        prewarm_n = min(prewarm_n, max(S, int(0.1 / max(cold / max(args.steps, 1), 1e-9))))
         t0 = time.perf_counter()
         for blk in range((prewarm_n + S - 1) // S):
             for sl in range(S):
