@@ -27,6 +27,8 @@ k2s[0].run()
 torch.cuda.synchronize()
 lib.mr_pnp_debug_set_stamps(None)
 s = st.cpu().numpy().reshape(nw, 8).astype(np.float64)
+s = s[s[:, 6] > 0]          # waves that ran the quad path (an object's last wave, in pair mode, leaves before the later stamps)
+nw = len(s)
 t0 = s[:, 0].min()
 s = (s - t0) / 100.0          # us
 names = ['start', 'params ready', 'loads issued', 'data arrived', 'arithmetic done', 'stores issued', 'stores complete']
