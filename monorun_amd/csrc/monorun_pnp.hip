@@ -1187,6 +1187,7 @@ int mr_epnp_ransac_batched(
     if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK)) {
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
+    a.stamps = g_stamps;
     sa.init_pose = init_pose; sa.init_mask = init_mask; sa.init_ok = init_valid; sa.diag = diag; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
     hipStream_t st = (hipStream_t)stream;
     // hypotheses solved for every object before the replayed loop is consulted: MR_EPNP_FIRST_ROUND bits of `flags` (1..30), else the

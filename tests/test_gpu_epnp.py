@@ -288,7 +288,7 @@ def test_workspace_contract_and_the_library_allocated_workspace(dev):
     lib = _lib.load()
     assert lib.mr_epnp_workspace_bytes(0, 784) == 0 and lib.mr_epnp_workspace_bytes(4, 3) == 0
     need = int(lib.mr_epnp_workspace_bytes(64, 784))
-    assert need > 64 * 30 * (25 * 4 + 39 * 8) and need % 256 == 0              # at least the samples and the candidates' results of every hypothesis
+    assert need > 64 * 30 * (25 * 4 + 12 * 8) and need % 256 == 0              # at least the samples and R | t of every hypothesis
     assert int(lib.mr_epnp_workspace_bytes(128, 784)) > need
     b = syn.make_batch(B=64, seed=77)
     x2d, istd, x3d, K, ur, vr, thr = [_t(dev, a) for a in syn.pnp_boundary(b, planar=True)]
