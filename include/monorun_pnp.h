@@ -167,6 +167,24 @@ int mr_epnp_ransac_batched(
 size_t mr_epnp_workspace_bytes(int B, int P);
 
 /*
+ * The same initialiser for SEVERAL calls in one launch set (1 <= ncalls <= 4): call c has its own correspondence tensors x2d[c] /
+ * istd[c] / x3d[c], camera cam_mats[c], thresholds ransac_thr[c] and outputs init_pose[c] / init_mask[c] / init_valid[c] / diag[c]
+ * (arrays of ncalls device pointers, read on the host); B objects per call, and P, the element strides, in_dtype, cam_batch, istd_thres,
+ * flags and max_iters are common (ransac_thr and diag: all NULL or none).  Results are those of ncalls calls of mr_epnp_ransac_batched,
+ * bit for bit.  Why it exists: HIP runs the launches of at most four streams side by side, and every stage of this initialiser is a
+ * latency chain that fills a fraction of the chip — a launch that carries the objects of two calls keeps eight calls' stages in flight on
+ * four streams (monorun_amd.PnPEpnpGroupLaunch; measured on MI355X: DESIGN.md section 3).  workspace: at least
+ * mr_epnp_workspace_bytes(ncalls * B, P) bytes (NULL: the library's pool, as above).
+ */
+int mr_epnp_ransac_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *ransac_thr, int B, int P,
+    float istd_thres, int flags, int max_iters,
+    double *const *init_pose, uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *diag,
+    void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * LM + covariance (stages 3 and 4 of mr_pnp_uncert_batched) from an EXTERNAL initialiser's result: init_mask (B,P) u8 is the
  * candidate = inlier set the LM sees (inlier_opt_only) and the mask the covariance uses, init_pose (B,4) f64 the start, init_valid
  * (B) u8 = 0 marks objects whose initialiser failed (valid = 0, zero pose, as pnp_uncert_cpu.py:119-125).  Everything else as

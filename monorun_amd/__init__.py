@@ -7,6 +7,6 @@ wire format), ``parallel`` (object sharding, RCCL exchange), ``synthetic`` (seed
 """
 from . import _lib  # noqa: F401
 from .ops import build_pnp, PnPUncert, pnp_uncert, u2d_pnp_cpu, PNP  # noqa: F401
-from .ops.least_squares.pnp_uncert import PnPLaunch, PnPEpnpLaunch, PnPPipeline, pnp_uncert_device  # noqa: F401
+from .ops.least_squares.pnp_uncert import PnPLaunch, PnPEpnpLaunch, PnPEpnpGroupLaunch, PnPPipeline, pnp_uncert_device  # noqa: F401
 
 __version__ = '0.1.0'

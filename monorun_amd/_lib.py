@@ -79,6 +79,8 @@ def load():
         vp, vp, vp, vp, vp, vp, vp]                 # valid, pose, cov, tr, mask, diag, stream
     lib.mr_epnp_ransac_batched.restype = i32
     lib.mr_epnp_ransac_batched.argtypes = [vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.mr_epnp_ransac_grouped.restype = i32
+    lib.mr_epnp_ransac_grouped.argtypes = [i32, vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.mr_epnp_workspace_bytes.restype = ctypes.c_size_t
     lib.mr_epnp_workspace_bytes.argtypes = [i32, i32]
     lib.mr_pnp_uncert_from_init_batched.restype = i32
@@ -135,5 +137,5 @@ def check(code):
 
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_spin', 'mr_pick_waves', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
-                    'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
+                    'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_ransac_grouped', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
                     'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

@@ -1161,26 +1161,33 @@ int mr_pnp_uncert_from_init_batched(
                              valid, pose, cov, tr_radius, inlier_mask, diag, stream);
 }
 
-int mr_epnp_ransac_batched(
-    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
-    const void *x3d, const int64_t *x3d_strides, int in_dtype,
-    const float *cam_mats, int cam_batch, const float *ransac_thr, int B, int P,
+static int epnp_ransac_launch(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *ransac_thr, int B, int P,
     float istd_thres, int flags, int max_iters,
-    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses,
+    double *const *init_pose, uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *diag, double *debug_hypotheses,
     void *workspace, size_t workspace_bytes, void *stream) {
-    if (B < 0 || P < 4 || P > 64 * kMaxChunks || max_iters < 1 || max_iters > kEpMaxIters) return MR_ERR_BAD_ARGUMENT;
+    if (ncalls < 1 || ncalls > kEpMaxGroup || B < 0 || P < 4 || P > 64 * kMaxChunks || max_iters < 1 || max_iters > kEpMaxIters) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
-    if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !init_pose || !init_mask || !init_valid)
-        return MR_ERR_BAD_ARGUMENT;
+    if ((long long)B * ncalls > 0x7fffffffll / kEpMaxIters) return MR_ERR_UNSUPPORTED;
+    if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !init_pose || !init_mask || !init_valid) return MR_ERR_BAD_ARGUMENT;
     if (cam_batch != 1 && cam_batch != B) return MR_ERR_BAD_ARGUMENT;
+    const bool with_thr = ransac_thr && ransac_thr[0], with_diag = diag && diag[0];
+    for (int c = 0; c < ncalls; ++c) {
+        if (!x2d[c] || !istd[c] || !x3d[c] || !cam_mats[c] || !init_pose[c] || !init_mask[c] || !init_valid[c]) return MR_ERR_BAD_ARGUMENT;
+        if ((ransac_thr && ransac_thr[c] != nullptr) != with_thr || (diag && diag[c] != nullptr) != with_diag) return MR_ERR_BAD_ARGUMENT;     // all or none
+    }
+    if (debug_hypotheses && ncalls != 1) return MR_ERR_BAD_ARGUMENT;
+    const size_t esize = in_dtype == MR_F64 ? 8 : (in_dtype == MR_F32 ? 4 : 2);
     EpnpStageArgs sa;
     memset(&sa, 0, sizeof sa);
     PnpArgs &a = sa.p;
-    a.x2d = x2d; a.istd = istd; a.x3d = x3d;
+    a.x2d = x2d[0]; a.istd = istd[0]; a.x3d = x3d[0];
     for (int i = 0; i < 3; ++i) { a.s2[i] = x2d_strides[i]; a.sw[i] = istd_strides[i]; a.s3[i] = x3d_strides[i]; }
-    a.K = cam_mats; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
-    a.ransac_thr = ransac_thr;
-    a.B = B; a.P = P; a.istd_thres = istd_thres; a.flags = flags;
+    a.K = cam_mats[0]; a.K_stride = (cam_batch == 1) ? 0 : 9; a.K_f64 = 0;
+    a.ransac_thr = with_thr ? ransac_thr[0] : nullptr;
+    a.B = B * ncalls; a.P = P; a.istd_thres = istd_thres; a.flags = flags;
     int mm = flags & MR_MEAN_MASK;
     if (mm == MR_MEAN_AUTO) mm = (istd_strides[1] == 1 && P > 1) ? MR_MEAN_PAIRWISE : MR_MEAN_SEQUENTIAL;
     a.mean_mode = mm;
@@ -1188,7 +1195,19 @@ int mr_epnp_ransac_batched(
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
     a.stamps = g_stamps;
-    sa.init_pose = init_pose; sa.init_mask = init_mask; sa.init_ok = init_valid; sa.diag = diag; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
+    sa.init_pose = init_pose[0]; sa.init_mask = init_mask[0]; sa.init_ok = init_valid[0]; sa.diag = with_diag ? diag[0] : nullptr; sa.dbg_hyp = debug_hypotheses; sa.max_iters = max_iters;
+    sa.ncalls = ncalls; sa.group_B = B;
+    for (int c = 0; c < ncalls; ++c) {
+        // pointers biased so that the GLOBAL object index c * B + i addresses object i of call c (epnp_stages.inc EpnpCallPtrs)
+        const long long o = (long long)c * B;
+        EpnpCallPtrs &q = sa.call[c];
+        q.x2d = (const char *)x2d[c] - o * x2d_strides[0] * (long long)esize;
+        q.istd = (const char *)istd[c] - o * istd_strides[0] * (long long)esize;
+        q.x3d = (const char *)x3d[c] - o * x3d_strides[0] * (long long)esize;
+        q.K = (const char *)cam_mats[c] - o * a.K_stride * (long long)sizeof(float);
+        q.ransac_thr = with_thr ? ransac_thr[c] - o : nullptr;
+        q.init_pose = init_pose[c] - o * 4; q.init_mask = init_mask[c] - o * P; q.init_ok = init_valid[c] - o; q.diag = with_diag ? diag[c] - o * 4 : nullptr;
+    }
     hipStream_t st = (hipStream_t)stream;
     // hypotheses solved for every object before the replayed loop is consulted: MR_EPNP_FIRST_ROUND bits of `flags` (1..30), else the
     // environment variable MR_EPNP_FIRST_ROUND, else 8
@@ -1201,6 +1220,28 @@ int mr_epnp_ransac_batched(
         case MR_F64: return launch_epnp_stages<double>(sa, workspace, workspace_bytes, first_round, st);
         default: return MR_ERR_UNSUPPORTED;
     }
+}
+
+int mr_epnp_ransac_batched(
+    const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,
+    const void *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *cam_mats, int cam_batch, const float *ransac_thr, int B, int P,
+    float istd_thres, int flags, int max_iters,
+    double *init_pose, uint8_t *init_mask, uint8_t *init_valid, float *diag, double *debug_hypotheses,
+    void *workspace, size_t workspace_bytes, void *stream) {
+    return epnp_ransac_launch(1, &x2d, x2d_strides, &istd, istd_strides, &x3d, x3d_strides, in_dtype, &cam_mats, cam_batch, &ransac_thr, B, P,
+                              istd_thres, flags, max_iters, &init_pose, &init_mask, &init_valid, &diag, debug_hypotheses, workspace, workspace_bytes, stream);
+}
+
+int mr_epnp_ransac_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *ransac_thr, int B, int P,
+    float istd_thres, int flags, int max_iters,
+    double *const *init_pose, uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *diag,
+    void *workspace, size_t workspace_bytes, void *stream) {
+    return epnp_ransac_launch(ncalls, x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, ransac_thr, B, P,
+                              istd_thres, flags, max_iters, init_pose, init_mask, init_valid, diag, nullptr, workspace, workspace_bytes, stream);
 }
 
 size_t mr_epnp_workspace_bytes(int B, int P) {

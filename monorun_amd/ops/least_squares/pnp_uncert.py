@@ -257,6 +257,49 @@ class PnPEpnpLaunch:
             _lib.check(code)
 
 
+class PnPEpnpGroupLaunch:
+    """Up to four prepared ``PnPEpnpLaunch`` objects of the same shape whose initialisers run as ONE launch set
+    (``mr_epnp_ransac_grouped``: every launch of csrc/epnp_stages.inc carries the objects of all members), followed by each
+    member's own LM + covariance launch, all on the stream ``run`` is given.  Members keep their inputs and outputs; results are
+    bit-identical to running them one by one.  Why: HIP runs the launches of at most four streams side by side and the
+    initialiser's stages are latency chains that fill a fraction of the chip, so a ``PnPPipeline`` of depth 4 that is fed groups
+    of two keeps EIGHT calls' stages in flight (measured on MI355X, reference flow, 1024-object calls: DESIGN.md section 3)."""
+
+    def __init__(self, launches):
+        self.members = list(launches)
+        n = len(self.members)
+        if not 1 <= n <= 4:
+            raise ValueError('PnPEpnpGroupLaunch takes 1 to 4 launches')
+        f = self.members[0]
+        self.lib, self.dev, self.B = f.lib, f.dev, f.B
+        ai = f.args_init
+        same = lambda m: (m.B == f.B and m.dev == f.dev and tuple(m.args_init[1]) == tuple(ai[1]) and tuple(m.args_init[3]) == tuple(ai[3]) and
+                          tuple(m.args_init[5]) == tuple(ai[5]) and m.args_init[6] == ai[6] and m.args_init[8] == ai[8] and m.args_init[11:15] == ai[11:15] and
+                          (m.args_init[9] is None) == (ai[9] is None) and (m.args_init[18] is None) == (ai[18] is None))
+        if not all(same(m) for m in self.members):
+            raise ValueError('the members of a group must share shape, strides, dtype, camera batching, thresholds and flags')
+        arr = lambda k: (ctypes.c_void_p * n)(*[m.args_init[k] for m in self.members])
+        self._arrays = [arr(k) for k in (0, 2, 4, 7, 9, 15, 16, 17, 18)]
+        x2d, istd, x3d, cam, thr, ipose, imask, ivalid, idiag = self._arrays
+        P = ai[11]
+        self.work = torch.empty(int(self.lib.mr_epnp_workspace_bytes(n * f.B, P)) if f.B > 0 else 0, device=f.dev, dtype=torch.uint8)
+        self.args = [n, x2d, ai[1], istd, ai[3], x3d, ai[5], ai[6], cam, ai[8], thr, f.B, P, ai[12], ai[13], ai[14],
+                     ipose, imask, ivalid, idiag, self.work.data_ptr(), self.work.numel()]
+
+    def run(self, stream=None):
+        if self.B == 0:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            code = self.lib.mr_epnp_ransac_grouped(*self.args, st)
+            for m in self.members:
+                if code:
+                    break
+                code = self.lib.mr_pnp_uncert_from_init_batched(*m.args_lm, st)
+        if code:
+            _lib.check(code)
+
+
 class PnPPipeline:
     """Several prepared launches in flight: ``submit`` issues them round-robin on ``depth`` internal HIP streams.
 

@@ -119,6 +119,52 @@ def _coord_map_args(coord_2d, dev):
     return m.data_ptr(), int(m.shape[1]), int(m.shape[2])
 
 
+def gen_coord_2d(h, w, pad_to=32, flip=False, scale=None, device=None):
+    """The image's coordinate map as the reference's data pipeline hands it to the RoI head — ``(1, 2, Hp, Wp)`` float32, channel 0 =
+    u (column index), channel 1 = v (row index) of the ORIGINAL image:
+
+      * ``LoadAnnotations3D._gen_coord_2d`` (/root/reference/monorun/datasets/pipelines/loading.py:67-78): ``np.mgrid[:h, :w]``, [u, v];
+      * ``flip``: RandomFlip3D's horizontal ``mmcv.imflip`` of the dense field (transforms.py:36-52): column x' holds u = w - 1 - x';
+      * ``pad_to``: Pad3D's ``mmcv.impad(..., padding_mode='edge')`` to the next multiple of ``size_divisor`` (transforms.py:55-74;
+        configs/kitti_car.py:220,238): rows / columns beyond the image REPLICATE the last row / column (0 = no padding).
+      These three are index operations and are pinned by fixture G9 (generated by calling the reference's function).
+      * ``scale`` (keep-ratio factor s of Resize3D, transforms.py:12-32; no shipped config uses it): the bilinear branch of
+        ``mmcv.imrescale`` for s >= 1 — cv2's half-pixel mapping of a linear ramp, u(x') = clip((x' + 0.5) / s - 0.5, 0, w - 1) —
+        applied before flip and padding as the pipeline orders them.  OpenCV is not in this image: unpinned; s < 1 ('area') is refused.
+
+    ``coord_2d=None`` in ``noc_decode`` / ``pose_from_head`` (bin centres written analytically) equals RoIAlign of this map exactly
+    where every sampling point of the RoI lies inside [0, w - 1] x [0, h - 1] of an unflipped, unscaled image; RoIs that hug or cross the
+    image border, flipped or rescaled images need the map."""
+    h, w = int(h), int(w)
+    if h < 1 or w < 1:
+        raise ValueError('gen_coord_2d: empty image')
+    f32 = dict(dtype=torch.float32, device=device)
+    if scale is None or float(scale) == 1.0:
+        u = torch.arange(w, **f32)
+        v = torch.arange(h, **f32)
+    else:
+        s = float(scale)
+        if s < 1.0:
+            raise NotImplementedError("gen_coord_2d: scale < 1 uses cv2's INTER_AREA (mmcv.imrescale), which is not restated")
+        ws, hs = int(w * s + 0.5), int(h * s + 0.5)                 # mmcv.rescale_size
+        # cv2.resize maps by the per-axis ratio src / dst; float64 arithmetic, float32 storage
+        u = ((torch.arange(ws, dtype=torch.float64, device=device) + 0.5) * (w / ws) - 0.5).clamp_(0, w - 1).to(torch.float32)
+        v = ((torch.arange(hs, dtype=torch.float64, device=device) + 0.5) * (h / hs) - 0.5).clamp_(0, h - 1).to(torch.float32)
+    if flip:
+        u = torch.flip(u, dims=[0])
+    hh, ww = int(v.numel()), int(u.numel())
+    d = int(pad_to) if pad_to else 1
+    hp, wp = -(-hh // d) * d, -(-ww // d) * d
+    if wp > ww:
+        u = torch.cat([u, u[-1:].expand(wp - ww)])
+    if hp > hh:
+        v = torch.cat([v, v[-1:].expand(hp - hh)])
+    out = torch.empty(1, 2, hp, wp, **f32)
+    out[0, 0] = u[None, :]
+    out[0, 1] = v[:, None]
+    return out
+
+
 def roi_align_avg(input, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned=True):
     """mmcv.ops.roi_align(input, rois, output_size, spatial_scale, sampling_ratio, 'avg', aligned) forward
     (``mr_roi_align_avg``).  input (N,C,H,W) f32 on the GPU, rois (K,5) [batch_idx, x1, y1, x2, y2] -> (K,C,oh,ow)."""

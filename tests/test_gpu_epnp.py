@@ -349,6 +349,60 @@ def test_prepared_reference_flow_launches_in_flight(dev):
     assert torch.equal(ls[0].valid, r[0]) and torch.equal(ls[0].pose, r[1]) and torch.equal(ls[0].cov, r[2]) and torch.equal(ls[0].mask, r[4])
 
 
+def test_grouped_calls_equal_the_calls_one_by_one(dev):
+    """mr_epnp_ransac_grouped / PnPEpnpGroupLaunch: the initialiser's launches carry the objects of up to four calls (separate input and
+    output tensors, shared workspace), each call's LM launch follows — bit-identical to the calls one by one: per-object cameras and a
+    shared one, with and without the diag output, groups of 2, 3 and 4, a group in flight next to others, and the argument checks."""
+    import ctypes
+    from monorun_amd import PnPEpnpLaunch, PnPEpnpGroupLaunch, PnPPipeline, _lib
+    lib = _lib.load()
+    mk = lambda seed, B=192: [_t(dev, a) for a in syn.pnp_boundary(syn.make_batch(B=B, seed=seed), planar=True)]
+    batches = [mk(900 + i) for i in range(7)]
+    for x in batches[4:6]:                                # two batches with a camera per object
+        x[3] = (x[3].reshape(1, 3, 3).repeat(192, 1, 1) * torch.linspace(0.97, 1.03, 192, device=dev)[:, None, None]).contiguous()
+    kw = dict(z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True)
+    def solo(x, diag=False):
+        l = PnPEpnpLaunch(*x[:6], epnp_ransac_thres=x[6], with_diag=diag, **kw); l.run(); torch.cuda.synchronize(); return l
+    refs = [solo(x, diag=(i < 2)) for i, x in enumerate(batches)]
+    def same(l, r):
+        return (torch.equal(l.valid, r.valid) and torch.equal(l.pose, r.pose) and torch.equal(l.cov, r.cov) and torch.equal(l.tr, r.tr) and torch.equal(l.mask, r.mask)
+                and torch.equal(l.init_pose, r.init_pose) and torch.equal(l.init_mask, r.init_mask) and torch.equal(l.init_valid, r.init_valid))
+    for members, diag in (([0, 1], True), ([2, 3, 6], False), ([0, 1, 2, 3], False), ([4, 5], False), ([6], False)):
+        ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], with_diag=diag, **kw) for i in members]
+        g = PnPEpnpGroupLaunch(ls)
+        g.run(); g.run(); torch.cuda.synchronize()
+        for l, i in zip(ls, members):
+            assert same(l, refs[i]), (members, i)
+            assert int(l.valid.sum()) > 150
+            if diag:
+                assert torch.equal(l.init_diag, refs[i].init_diag) and torch.equal(l.diag, refs[i].diag)
+    # groups in flight: three groups of two on a depth-3 pipeline, twice over
+    ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], **kw) for i in (0, 1, 2, 3, 6, 0)]
+    groups = [PnPEpnpGroupLaunch(ls[2 * k:2 * k + 2]) for k in range(3)]
+    pipe = PnPPipeline(dev, depth=3, record_events=False)
+    for rep in range(2):
+        for k, g in enumerate(groups):
+            pipe.submit(g, slot=k)
+    pipe.drain()
+    for l, i in zip(ls, (0, 1, 2, 3, 6, 0)):
+        assert same(l, refs[i])
+    # members must agree in shape / camera batching; more than four calls and mixed thresholds are refused by the library
+    with pytest.raises(ValueError):
+        PnPEpnpGroupLaunch([refs[0], refs[4]])
+    with pytest.raises(ValueError):
+        PnPEpnpGroupLaunch([refs[0], solo(mk(77, B=64))])
+    with pytest.raises(ValueError):
+        PnPEpnpGroupLaunch(refs[:5])
+    g = PnPEpnpGroupLaunch([refs[2], refs[3]])
+    bad = list(g.args); bad[0] = 5
+    assert lib.mr_epnp_ransac_grouped(*bad, None) == -1
+    bad = list(g.args); thr = (ctypes.c_void_p * 2)(g.args[10][0], None); bad[10] = thr
+    assert lib.mr_epnp_ransac_grouped(*bad, None) == -1
+    bad = list(g.args); bad[21] = 1024
+    assert lib.mr_epnp_ransac_grouped(*bad, None) == -1                   # workspace too small for the whole group
+    torch.cuda.synchronize()
+
+
 def test_fp64_storage_gives_the_fp32_results(dev):
     """fp64 correspondence tensors holding float32 values: the initialiser reads correspondences as float32 (as the reference hands
     them to cv2), so every output equals the fp32-storage run's — both layouts, through the initialiser and the LM launch."""
