@@ -16,6 +16,12 @@ from .builder import PNP
 
 _DTYPES = {torch.float32: _lib.MR_F32, torch.float16: _lib.MR_F16, torch.float64: _lib.MR_F64}
 
+# What `build_pnp(dict(type='PnPUncert', ...))` from the reference's own config dict, `pnp_uncert`, `u2d_pnp_cpu` and the pose head run when
+# nobody says otherwise: the REFERENCE's flow — cv2.solvePnPRansac(EPNP, 30 iterations) restated on the GPU, then the LM + covariance
+# (pnp_uncert_cpu.py:33-68).  'k0' (this repository's one-launch consensus initialiser: ~5 x the throughput, the same LM, inlier sets that
+# differ from the reference flow's on ~13 % of the objects) is an explicit fast mode since round 5.
+DEFAULT_INITIALISER = 'epnp'
+
 
 def _strides(t):
     return (ctypes.c_int64 * 3)(*t.stride())
@@ -211,7 +217,12 @@ class PnPEpnpLaunch:
     overlap almost for free."""
 
     def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=0.6,
-                 epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False, first_round=None):
+                 epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False, first_round=None,
+                 out=None, mask=None, work=None):
+        """out: an object with valid / pose / cov / tr tensors to write the results into (e.g. the typed views of
+        parallel.PackedResults: the kernel then writes straight into the buffer a collective sends); mask: the (B,P) uint8 inlier-mask
+        buffer; work: a uint8 workspace of at least mr_epnp_workspace_bytes(B, P) bytes that SEVERAL launches may share when they
+        only ever run on one stream (stream order keeps that safe).  All three default to tensors of the launch's own."""
         self.lib = lib = _lib.load()
         dev = coords_2d.device
         if dev.type != 'cuda':
@@ -229,12 +240,18 @@ class PnPEpnpLaunch:
         self.init_mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
         self.init_valid = torch.empty(B, device=dev, dtype=torch.uint8)
         self.init_diag = torch.empty(B, 4, **f32) if with_diag else None
-        self.work = torch.empty(int(lib.mr_epnp_workspace_bytes(B, P)) if B > 0 else 0, device=dev, dtype=torch.uint8)
-        self.valid = torch.empty(B, device=dev, dtype=torch.uint8)
-        self.pose = torch.empty(B, 4, **f32)
-        self.cov = torch.empty(B, 4, 4, **f32)
-        self.tr = torch.empty(B, **f32)
-        self.mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+        need = int(lib.mr_epnp_workspace_bytes(B, P)) if B > 0 else 0
+        self.work = work if work is not None else torch.empty(need, device=dev, dtype=torch.uint8)
+        assert self.work.dtype == torch.uint8 and self.work.numel() >= need and self.work.data_ptr() % 256 == 0
+        if out is None:
+            self.valid = torch.empty(B, device=dev, dtype=torch.uint8)
+            self.pose = torch.empty(B, 4, **f32)
+            self.cov = torch.empty(B, 4, 4, **f32)
+            self.tr = torch.empty(B, **f32)
+        else:
+            self.valid, self.pose, self.cov, self.tr = out.valid, out.pose, out.cov, out.tr
+        self.mask = mask if mask is not None else torch.empty(B, P, device=dev, dtype=torch.uint8)
+        assert self.mask.shape == (B, P) and self.mask.dtype == torch.uint8 and self.mask.is_contiguous()
         self.diag = torch.empty(B, 4, **f32) if with_diag else None
         self.B = B
         head = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[x2d.dtype], cam.data_ptr(), cam.shape[0]]
@@ -265,7 +282,9 @@ class PnPEpnpGroupLaunch:
     initialiser's stages are latency chains that fill a fraction of the chip, so a ``PnPPipeline`` of depth 4 that is fed groups
     of two keeps EIGHT calls' stages in flight (measured on MI355X, reference flow, 1024-object calls: DESIGN.md section 3)."""
 
-    def __init__(self, launches):
+    def __init__(self, launches, work=None):
+        """work: a uint8 workspace of at least mr_epnp_workspace_bytes(len(launches) * B, P) bytes (shared between groups that only
+        ever run on one stream), or None to allocate one."""
         self.members = list(launches)
         n = len(self.members)
         if not 1 <= n <= 4:
@@ -282,7 +301,9 @@ class PnPEpnpGroupLaunch:
         self._arrays = [arr(k) for k in (0, 2, 4, 7, 9, 15, 16, 17, 18)]
         x2d, istd, x3d, cam, thr, ipose, imask, ivalid, idiag = self._arrays
         P = ai[11]
-        self.work = torch.empty(int(self.lib.mr_epnp_workspace_bytes(n * f.B, P)) if f.B > 0 else 0, device=f.dev, dtype=torch.uint8)
+        need = int(self.lib.mr_epnp_workspace_bytes(n * f.B, P)) if f.B > 0 else 0
+        self.work = work if work is not None else torch.empty(need, device=f.dev, dtype=torch.uint8)
+        assert self.work.dtype == torch.uint8 and self.work.numel() >= need and self.work.data_ptr() % 256 == 0
         self.args = [n, x2d, ai[1], istd, ai[3], x3d, ai[5], ai[6], cam, ai[8], thr, f.B, P, ai[12], ai[13], ai[14],
                      ipose, imask, ivalid, idiag, self.work.data_ptr(), self.work.numel()]
 
@@ -466,7 +487,7 @@ def exact_hessian_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range
 
 
 def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
-               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser='k0', cov_symeig_rule=False,
+               epnp_ransac_thres=None, inlier_opt_only=False, forward_exact_hessian=False, use_6dof=False, initialiser=None, cov_symeig_rule=False,
                epnp_first_round=None):
     """Functional form of the op on torch tensors (argument names and defaults: pnp_uncert.py:7-11 of the reference).
 
@@ -476,10 +497,12 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     longer runs on torch >= 2): pose_cov = inverse of the exact Hessian of the masked cost (hessian.py:5-64) instead of
     inverse(J^T J) — a second launch (exact_hessian_device); ignored together with use_6dof=True (the 6-DoF covariance is the
     solver's J^T J).
-    initialiser (not a reference keyword): 'k0' = this repository's deterministic consensus initialiser inside the fused kernel (one
-    launch); 'epnp' = the reference's own initialiser — cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP),
-    pnp_uncert_cpu.py:33-68 — as its own sequence of launches in front of the LM launch (the published algorithm as DESIGN.md §5 restates
-    it: inlier sets, start pose and hence the returned pose are then the reference flow's, up to what OpenCV's own build would do).
+    initialiser (not a reference keyword; default = DEFAULT_INITIALISER = 'epnp'): 'epnp' = the reference's own initialiser —
+    cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP), pnp_uncert_cpu.py:33-68 — as its own sequence of launches in front
+    of the LM launch (the published algorithm as DESIGN.md §5 restates it: inlier sets, start pose and hence the returned pose are the
+    reference flow's, up to what OpenCV's own build would do); 'k0' = the explicit FAST MODE: this repository's deterministic consensus
+    initialiser inside the fused kernel (one launch, ~5 x the throughput, inlier sets that differ from the reference flow's on ~13 % of
+    the objects).
     epnp_first_round (with initialiser='epnp'; not a reference keyword): how many of the 30 speculative RANSAC hypotheses are solved for
     every object before the replayed loop is consulted (default 8; the rest only where the loop wants them; 30 = one round, the setting
     for outlier-heavy candidate sets one call at a time).  Never changes a result.
@@ -503,6 +526,8 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
             dev = torch.device('cuda', torch.cuda.current_device())
             mv = lambda t: t.to(dev) if t is not None else None
             coords_2d, coords_2d_istd, coords_3d = mv(coords_2d), mv(coords_2d_istd), mv(coords_3d)
+        if initialiser is None:
+            initialiser = DEFAULT_INITIALISER
         if initialiser == 'epnp':
             ini, imask, ivalid, _, _ = epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd_thres=epnp_istd_thres,
                                                           epnp_ransac_thres=epnp_ransac_thres, first_round=epnp_first_round)
@@ -539,14 +564,16 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
 class PnPUncert(torch.nn.Module):
 
     def __init__(self, z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, coord_istd_normalize=False,
-                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser='k0', epnp_first_round=None, cov_symeig_rule=False):
+                 forward_exact_hessian=False, use_6dof=False, eps=1e-6, initialiser=None, epnp_first_round=None, cov_symeig_rule=False):
         """Module form (constructor keywords of the reference, pnp_uncert.py:93-99; no parameters, no buffers).
         epnp_istd_thres: a point is an istd inlier when both of its istd components reach this factor times the object's
         mean; inlier_opt_only: the LM refines on the inlier set only; coord_istd_normalize: divide the istd map by its
         per-object mean (clamped at eps) first.  initialiser ('k0' | 'epnp'), epnp_first_round, cov_symeig_rule (not reference
-        keywords): see ``pnp_uncert``.  THE DEFAULT INITIALISER IS NOT THE REFERENCE'S: the reference's own config dict builds the
-        one-launch K0 path; ``initialiser='epnp'`` selects the reference's flow."""
+        keywords): see ``pnp_uncert``.  The reference's own config dict builds the REFERENCE's flow (initialiser='epnp', the default since
+        round 5); ``initialiser='k0'`` selects the one-launch fast mode."""
         super().__init__()
+        if initialiser is None:
+            initialiser = DEFAULT_INITIALISER
         if initialiser not in ('k0', 'epnp'):
             raise ValueError(f"initialiser must be 'k0' or 'epnp', got {initialiser!r}")
         if cov_symeig_rule and use_6dof:

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from ... import _lib
-from .pnp_uncert import epnp_ransac_device, pnp_uncert_device, pnp_uncert_from_init_device
+from .pnp_uncert import DEFAULT_INITIALISER, epnp_ransac_device, pnp_uncert_device, pnp_uncert_from_init_device
 
 
 def _to_dev(a, dev):
@@ -25,7 +25,7 @@ def _to_dev(a, dev):
 
 
 def u2d_pnp_cpu(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
-                epnp_ransac_thres=None, inlier_opt_only=False, with_pose_cov=True, initialiser='k0', epnp_first_round=None):
+                epnp_ransac_thres=None, inlier_opt_only=False, with_pose_cov=True, initialiser=None, epnp_first_round=None):
     """Batched pose solve on numpy arrays (keyword names and defaults are the reference's, pnp_uncert_cpu.py:128-135).
 
     Inputs, B objects with P correspondences each:
@@ -33,9 +33,10 @@ def u2d_pnp_cpu(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range
       object-frame points; cam_mats (B|1,3,3); u_range / v_range (B|1,2) clip intervals of the projection; z_min depth
       clamp; epnp_istd_thres the istd-inlier factor; epnp_ransac_thres (B,) consensus thresholds in pixels or None;
       inlier_opt_only: refine on the inlier set only; with_pose_cov: also return the covariance.
-      initialiser (not a reference keyword): 'k0' = the fused kernel's own deterministic consensus initialiser (one launch, the
-      default); 'epnp' = the reference's — cv2.solvePnPRansac(..., iterationsCount=30, flags=SOLVEPNP_EPNP) / cv2.solvePnP without a
-      threshold (pnp_uncert_cpu.py:33-68), restated on the GPU — in front of the same LM: the flow this function has in the reference.
+      initialiser (not a reference keyword): 'epnp' (the default since round 5) = the reference's — cv2.solvePnPRansac(...,
+      iterationsCount=30, flags=SOLVEPNP_EPNP) / cv2.solvePnP without a threshold (pnp_uncert_cpu.py:33-68), restated on the GPU — in
+      front of the same LM: the flow this function has in the reference; 'k0' = the fast mode, the fused kernel's own deterministic
+      consensus initialiser (one launch).
       epnp_first_round: see ``pnp_uncert``.
     Output 6-tuple (float32 / bool numpy arrays):
       ret_val (B,) success flags, yaw (B,1), t_vec (B,3), pose_cov (B,4,4) = (J^T J)^-1 of [yaw, t] with the solver's
@@ -55,6 +56,8 @@ def u2d_pnp_cpu(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     x2d, istd, x3d, cam, ur, vr = _to_dev(coords_2d, dev), _to_dev(coords_2d_istd, dev), _to_dev(coords_3d, dev), t(cam_mats), t(u_range), t(v_range)
     thr = t(epnp_ransac_thres) if epnp_ransac_thres is not None else None
+    if initialiser is None:
+        initialiser = DEFAULT_INITIALISER
     if initialiser == 'epnp':
         ini, imask, ivalid, _, _ = epnp_ransac_device(x2d, istd, x3d, cam, epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=thr, first_round=epnp_first_round)
         valid, pose, cov, tr, mask, _ = pnp_uncert_from_init_device(x2d, istd, x3d, cam, ur, vr, ini, imask, ivalid, z_min=z_min,

@@ -464,14 +464,15 @@ class UncertPropPnPOptimizer(nn.Module):
 def pose_from_head(pose_head, all_pred, labels, flip, dim, dim_var, rois, cam_intrinsic, img_shape,
                    apply_cov_correction=True, fused=True, **decode_kw):
     """NOC-head output -> pose results dict (what monorun_roi_head.py:509-534 produces).
-    fused=True: ONE launch (decode inside the PnP kernel); fused=False: K2 then the PnP kernel (two launches,
-    the decoded maps are materialised) — both give bit-identical results.  The one-launch kernel runs this repository's initialiser
-    K0; a head whose ``pnp`` was built with ``initialiser='epnp'`` (the reference's flow, uncert_prop_pnp_optimizer.py:86-95 ->
-    pnp_uncert_cpu.py:33-68), ``forward_exact_hessian``, ``coord_istd_normalize`` or ``cov_symeig_rule`` takes the K2 + module path
+    A head built from the reference's config dict runs the REFERENCE's flow (uncert_prop_pnp_optimizer.py:86-95 ->
+    pnp_uncert_cpu.py:33-68): K2, the EPnP / RANSAC initialiser's launches, the LM launch.  A head whose ``pnp`` says
+    ``initialiser='k0'`` (the fast mode) runs, with fused=True, ONE launch (decode inside the PnP kernel, this repository's initialiser
+    K0), with fused=False K2 then the PnP kernel (two launches, the decoded maps are materialised) — bit-identical results.
+    ``initialiser='epnp'``, ``forward_exact_hessian``, ``coord_istd_normalize`` or ``cov_symeig_rule`` take the K2 + module path
     whatever ``fused`` says."""
     p = pose_head.pnp
     if fused and (getattr(p, 'forward_exact_hessian', False) or getattr(p, 'coord_istd_normalize', False) or getattr(p, 'cov_symeig_rule', False)
-                  or getattr(p, 'initialiser', 'k0') != 'k0'):
+                  or getattr(p, 'initialiser', 'epnp') != 'k0'):
         # options the one-launch kernel does not implement — among them the reference's own initialiser (initialiser='epnp': its
         # launches read the decoded maps) — take the module path, which honours them: K2, then PnPUncert.forward
         fused = False
@@ -536,7 +537,7 @@ class PoseFromHeadLaunch:
             raise ValueError('PoseFromHeadLaunch prepares fixed launches: forward_exact_hessian / coord_istd_normalize / cov_symeig_rule '
                              'need pose_from_head (module path)')
         self._epnp = None
-        if getattr(p, 'initialiser', 'k0') == 'epnp':
+        if getattr(p, 'initialiser', 'epnp') == 'epnp':
             # the reference's initialiser: its launches read the decoded maps, so the prepared form is K2 (prepared) -> the initialiser's
             # launches + the LM launch (PnPEpnpLaunch) -> calibration / distance correction as three in-place tensor operations
             from .ops.least_squares.pnp_uncert import PnPEpnpLaunch
@@ -551,8 +552,11 @@ class PoseFromHeadLaunch:
             ep = PnPEpnpLaunch(_planar_view(d['coords_2d']), _planar_view(d['coords_2d_istd']), _planar_view(d['coords_3d']), self.inputs['cam_intrinsic'],
                                ur, vr, z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, epnp_ransac_thres=d['ransac_thr'],
                                inlier_opt_only=p.inlier_opt_only, flags=flags, first_round=getattr(p, 'epnp_first_round', None))
-            s_ = torch.exp(pose_head.cov_calib_logscale.detach().to(**f32))
-            self._epnp = dict(k2=k2, ep=ep, scale=(s_ * s_[:, None]).contiguous(), sd=float(ref_length * ref_focal_y * target_std) if apply_cov_correction else 0.0)
+            # the calibration reads the LIVE parameter on every run / replay (an alias of it when the head lives on the launch device in
+            # float32, like the fused launch's): weights loaded or updated in place after this object was built are honoured, also by a
+            # captured graph
+            ls = pose_head.cov_calib_logscale.detach().to(**f32)
+            self._epnp = dict(k2=k2, ep=ep, logscale=ls, sd=float(ref_length * ref_focal_y * target_std) if apply_cov_correction else 0.0)
             self.out = dict(ret_val_u8=ep.valid, pose=ep.pose, pose_cov_pred=ep.cov, tr_radius=ep.tr, inlier_mask_u8=ep.mask,
                             dimensions_pred=d['dims'], dimensions_var=d['dims_var'], pose_cov_calib=torch.empty(B, 4, 4, **f32))
             o = self.out
@@ -601,7 +605,8 @@ class PoseFromHeadLaunch:
                 e['ep'].run(ts.cuda_stream)
                 with torch.cuda.stream(ts):
                     o = self.out
-                    torch.mul(o['pose_cov_pred'], e['scale'], out=o['pose_cov_calib'])                       # (s s^T) * cov   (uncert_prop_pnp_optimizer.py:96-97)
+                    s_ = torch.exp(e['logscale'])
+                    torch.mul(o['pose_cov_pred'], s_ * s_[:, None], out=o['pose_cov_calib'])                  # (s s^T) * cov   (uncert_prop_pnp_optimizer.py:96-97)
                     if e['sd'] > 0.0:                                                                       # cov_correction  (monorun_roi_head.py:530-534)
                         o['pose_cov_calib'].mul_((e['sd'] / torch.norm(o['t_vec_pred'], p=2, dim=1)).square().view(-1, 1, 1))
         elif self.B:

@@ -55,8 +55,15 @@ def test_ops_surface_mirrors_reference():
     assert (m.z_min, m.epnp_istd_thres, m.inlier_opt_only, m.coord_istd_normalize, m.forward_exact_hessian, m.use_6dof, m.eps) == \
            (0.5, 0.6, True, False, False, False, 1e-6)
     assert len(list(m.state_dict())) == 0                       # no parameters or buffers, like the reference
+    assert m.initialiser == 'epnp'                              # the reference's config dict builds the REFERENCE's flow
     d = PnPUncert()
-    assert (d.z_min, d.epnp_istd_thres, d.inlier_opt_only) == (0.5, 0.6, True)
+    assert (d.z_min, d.epnp_istd_thres, d.inlier_opt_only, d.initialiser) == (0.5, 0.6, True, 'epnp')
+    assert build_pnp(dict(type='PnPUncert', initialiser='k0')).initialiser == 'k0'       # the explicit fast mode
+    import inspect
+    from monorun_amd.ops import pnp_uncert, u2d_pnp_cpu
+    from monorun_amd.ops.least_squares.pnp_uncert import DEFAULT_INITIALISER
+    assert DEFAULT_INITIALISER == 'epnp'
+    assert inspect.signature(pnp_uncert).parameters['initialiser'].default is None and inspect.signature(u2d_pnp_cpu).parameters['initialiser'].default is None
     with pytest.raises(TypeError):                               # the reference's latent default-dict bug is preserved:
         build_pnp(dict(type='PnPUncert', backward_exact_hessian=True))   # pnp_uncert.py:93-99 does not accept it
     with pytest.raises(KeyError):

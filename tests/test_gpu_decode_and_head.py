@@ -4,6 +4,10 @@ import numpy as np
 import pytest
 import torch
 
+# the one-launch FAST MODE these tests exercise (decode fused into the PnP kernel runs this repository's K0 initialiser); a head built from
+# the reference's config dict runs the reference's flow since round 5 (tests/test_gpu_epnp.py, test_reference_flow_* below)
+K0_PNP = dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False, initialiser='k0')
+
 from monorun_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -120,7 +124,7 @@ def test_tail_end_to_end_two_launches(dev, orc):
     logscale = np.array([0.3, -0.2, 0.1, 0.5], np.float32)
     ref_calib = orc.cov_correction(orc.cov_calib(ref[3], logscale), ref[2])
     # product
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=K0_PNP).to(dev)
     with torch.no_grad():
         head.cov_calib_logscale.copy_(torch.from_numpy(logscale))
         t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
@@ -164,7 +168,7 @@ def test_fused_head_to_pose_matches_two_launches_everywhere(dev, g3):
         dec = noc_decode(t(ap), t(lab), t(g3['flip']), t(g3['dim']), t(dv) if dv is not None else None, t(rois), **kw)
         ur = torch.tensor([[-200.0, 1442.0]], device=dev); vr = torch.tensor([[-200.0, 575.0]], device=dev)
         ref = pnp_uncert(_planar_view(dec['coords_2d']), _planar_view(dec['coords_2d_istd']), _planar_view(dec['coords_3d']), K, ur, vr,
-                         0.5, 0.6, dec['ransac_thr'], True)
+                         0.5, 0.6, dec['ransac_thr'], True, initialiser='k0')
         torch.cuda.synchronize()
         for a, b_ in zip(out[:5], ref):
             assert torch.equal(a, b_)
@@ -182,7 +186,7 @@ def test_fused_calibration_and_distance_correction(dev, g3):
     rois = np.concatenate([rois, rois + rng.uniform(30, 200, (B, 2))], 1).astype(np.float32)
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
     K = t(syn.KITTI_K[None].astype(np.float32))
-    head = ph.UncertPropPnPOptimizer().to(dev)
+    head = ph.UncertPropPnPOptimizer(pnp=K0_PNP).to(dev)
     with torch.no_grad():
         head.cov_calib_logscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.45]))
     args = (t(g3['all_pred']), t(g3['labels']), t(g3['flip']), t(g3['dim']), t(g3['dim_var']), t(rois), K, (375, 1242))
@@ -225,7 +229,7 @@ def test_prepared_and_graph_launch_for_the_per_image_regime(dev, orc):
     """PoseFromHeadLaunch (arguments built once over static buffers; optionally a HIP-graph replay) gives exactly what
     pose_from_head gives, also after the static inputs were overwritten with the next image's data."""
     from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head, PoseFromHeadLaunch
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=K0_PNP).to(dev)
     with torch.no_grad():
         head.cov_calib_logscale.copy_(torch.tensor([0.2, -0.1, 0.0, 0.4]))
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
@@ -283,7 +287,7 @@ def test_pose_head_honours_module_options_the_one_launch_kernel_lacks(dev, orc):
     b = syn.make_batch(B=40, seed=8)
     all_pred, dim = syn.encode_head_outputs(b, seed=8)
     args = (t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), (syn.IMG_H, syn.IMG_W, 3))
-    cfg = dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True)
+    cfg = dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, initialiser='k0')
     plain = UncertPropPnPOptimizer(pnp=dict(cfg, forward_exact_hessian=False)).to(dev)
     exact = UncertPropPnPOptimizer(pnp=dict(cfg, forward_exact_hessian=True)).to(dev)
     with torch.no_grad():
@@ -327,7 +331,7 @@ def test_fused_head_to_pose_on_70000_objects(dev):
     b = syn.make_batch(B=nd, seed=21)
     all_pred, dim = syn.encode_head_outputs(b, seed=21)
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=K0_PNP).to(dev)
     shape = (syn.IMG_H, syn.IMG_W, 3)
     with torch.no_grad():
         small = pose_from_head(head, t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), shape)
@@ -349,7 +353,7 @@ def test_fused_path_on_56x56_tiles(dev):
     b = syn.make_batch(B=64, hw=56, seed=5)
     all_pred, dim = syn.encode_head_outputs(b, seed=5)
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=K0_PNP).to(dev)
     args = (head, t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), (syn.IMG_H, syn.IMG_W, 3))
     with torch.no_grad():
         r1, r2 = pose_from_head(*args), pose_from_head(*args, fused=False)
@@ -364,7 +368,7 @@ def test_prepared_launches_keep_a_converted_coord_map_alive(dev):
     that copy on every run() / replay(), so it must own it (the copy was released when __init__ returned).  An fp16
     and a non-contiguous fp64 map must give what the eager call gives, also after other allocations have churned the pool."""
     from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head, PoseFromHeadLaunch, NocDecodeLaunch, noc_decode
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=K0_PNP).to(dev)
     b = syn.make_batch(B=40, seed=11)
     all_pred, dim = syn.encode_head_outputs(b, seed=11)
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
@@ -503,8 +507,8 @@ def test_head_built_with_the_reference_initialiser_is_honoured_everywhere(dev, o
     ref_k0 = orc.u2d_pnp(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
     assert not np.array_equal(ref[5], ref_k0[5])                       # the two initialisers DO differ on this batch: the test can tell them apart
     t = lambda a, dt=None: torch.from_numpy(np.asarray(a)).to(dev) if dt is None else torch.from_numpy(np.asarray(a)).to(device=dev, dtype=dt)
-    head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False,
-                                           initialiser='epnp')).to(dev)
+    head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False)).to(dev)      # the reference's own config dict (configs/kitti_car.py:118-126)
+    assert head.pnp.initialiser == 'epnp'
     args = (t(all_pred), t(b['labels']), False, t(dim), None, t(b['rois']), t(b['K']), (syn.IMG_H, syn.IMG_W, 3))
 
     def check(res, what):
@@ -531,7 +535,7 @@ def test_head_built_with_the_reference_initialiser_is_honoured_everywhere(dev, o
     pl.replay(); torch.cuda.synchronize()
     assert all(torch.equal(out[k], keep[k]) for k in keep)
     # ... and the numpy-level driver the reference's flow is written in
-    rr = u2d_pnp_cpu(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True, initialiser='epnp')
+    rr = u2d_pnp_cpu(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
     assert np.array_equal(rr[0], ref[0]) and np.array_equal(rr[5], ref[5])
     assert np.abs(rr[2] - ref[2])[ref[0]].max() <= 1e-4 and np.abs(np.angle(np.exp(1j * (rr[1] - ref[1]))))[ref[0]].max() <= 1e-4
     with pytest.raises(ValueError):

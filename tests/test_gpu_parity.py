@@ -222,8 +222,13 @@ def test_torch_level_dropin_api(dev, orc, batch64):
     assert ret.dtype == torch.bool and ret.shape == (64,) and r_vec.shape == (64, 1) and t_vec.shape == (64, 3)
     assert cov.shape == (64, 4, 4) and mask.dtype == torch.bool and mask.shape == (64, 784)
     assert all(o.device.type == 'cuda' for o in (ret, r_vec, t_vec, cov, mask)) and cov.dtype == torch.float32
-    ref = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True)
-    assert np.array_equal(mask.cpu().numpy(), ref[5]) and np.abs(t_vec.cpu().numpy() - ref[2]).max() <= POSE_TOL
+    ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True)        # the module built from the reference's dict runs the REFERENCE's flow
+    assert m.initialiser == 'epnp' and np.array_equal(mask.cpu().numpy(), ref[5]) and np.abs(t_vec.cpu().numpy() - ref[2]).max() <= POSE_TOL
+    # ... and the explicit fast mode the K0 specification's
+    mk = build_pnp(dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False, initialiser='k0'))
+    rk = mk(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), t(thr))
+    refk = orc.u2d_pnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True)
+    assert np.array_equal(rk[4].cpu().numpy(), refk[5]) and np.abs(rk[2].cpu().numpy() - refk[2]).max() <= POSE_TOL
     # host tensors in -> host tensors out (staged through the GPU, never solved on the CPU)
     ret_h, r_h, t_h, cov_h, mask_h = pnp_uncert(torch.from_numpy(x2d), torch.from_numpy(istd), torch.from_numpy(x3d), torch.from_numpy(K),
                                                 torch.from_numpy(ur), torch.from_numpy(vr), 0.5, 0.6, torch.from_numpy(thr), True)
@@ -396,7 +401,7 @@ def test_adversarial_inputs_terminate_and_match_oracle_validity(dev, orc):
 
 
 def test_hip_kernel_against_the_reference_initialiser_restated(dev, orc):
-    """R5: the HIP kernel (K0 initialiser) against the reference's flow with its OWN initialiser restated (EPnP inside
+    """R5: the explicit FAST MODE (initialiser='k0', the one-launch kernel; not the default since round 5) against the reference's flow with its OWN initialiser restated (EPnP inside
     OpenCV's RANSAC loop, oracle/epnp.inc) on a config-2 batch, compared after the LM: same validity, the same inlier set
     for the large majority of objects, poses within a small fraction of the posterior standard deviation
     (distribution: DESIGN.md §5; CPU counterpart: tests/test_oracle_epnp.py)."""
@@ -555,7 +560,7 @@ def test_reference_eigenvalue_rule_for_ill_conditioned_hessians(dev, orc):
     init = np.concatenate([b['gt_yaw'][:, None], b['gt_t']], 1)
     outs = {}
     for rule in (False, True):
-        outs[rule] = [o.cpu().numpy() for o in pnp_uncert(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), 0.5, 0.6, None, False, cov_symeig_rule=rule)]
+        outs[rule] = [o.cpu().numpy() for o in pnp_uncert(t(x2d), t(istd), t(x3d), t(K), t(ur), t(vr), 0.5, 0.6, None, False, cov_symeig_rule=rule, initialiser='k0')]
     h_valid, h_cov, h_lam = orc.cov_symeig_rule(outs[False][0], outs[False][3])
     clear = np.abs((h_lam[:, 0] / h_lam[:, 1]) / 1e-6 - 1.0) > 0.05
     assert np.array_equal(outs[True][0][clear], h_valid[clear])

@@ -113,7 +113,7 @@ def test_gpu_decode_with_coord_map(batch64):
     assert (a['coords_2d'][:, 1] - c['coords_2d'][:, 1]).abs().max().item() < 2e-3
     # fused == two-launch with a map
     K = torch.tensor([[[707.0912, 0, 601.8873], [0, 707.0912, 183.1104], [0, 0, 1]]], device=dev)
-    head = ph.UncertPropPnPOptimizer().to(dev)
+    head = ph.UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, initialiser='k0')).to(dev)     # the one-launch fast mode
     r1 = ph.pose_from_head(head, all_pred, labels, False, dim, dim_var, rois, K, (H, W), fused=True, coord_2d=ident)
     r2 = ph.pose_from_head(head, all_pred, labels, False, dim, dim_var, rois, K, (H, W), fused=False, coord_2d=ident)
     for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred'):

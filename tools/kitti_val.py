@@ -189,8 +189,8 @@ def parse_args(argv=None):
     ap.add_argument('--out', default=None, help='directory for the KITTI result files')
     ap.add_argument('--img-shape', type=int, nargs=2, default=(375, 1242))
     ap.add_argument('--gpus', type=int, default=1, help='shard the objects over this many GPUs (the script starts its own ranks)')
-    ap.add_argument('--initialiser', choices=('k0', 'epnp'), default='k0',
-                    help="'k0': the one-launch kernel's own initialiser (default); 'epnp': the reference's cv2.solvePnPRansac(EPNP) restated on the GPU")
+    ap.add_argument('--initialiser', choices=('k0', 'epnp'), default='epnp',
+                    help="'epnp' (default): the reference's cv2.solvePnPRansac(EPNP) restated on the GPU; 'k0': the one-launch kernel's own initialiser (fast mode)")
     ap.add_argument('--images-per-batch', type=int, default=16, help='images whose objects share one launch (and, sharded, one all-gather)')
     return ap.parse_args(argv)
 
