@@ -252,14 +252,14 @@ def run(args):
 
     # exchange: a private RCCL communicator driven directly (ncclAllGather on a high-priority side stream, ~5 us of host time per
     # call); MR_BENCH_COMM=torch, or any failure to set it up, falls back to torch.distributed's (synchronous) all-gather
-    rccl = None
+    rccl, rccl_why = None, None
     if use_dist and not oversub and os.environ.get('MR_BENCH_COMM', 'rccl') == 'rccl':
-        try:
-            from monorun_amd.parallel import RcclAllGather
-            rccl = RcclAllGather(dev)
-        except Exception as e:                                   # noqa: BLE001 — any setup problem: use the c10d path
-            print(f'[bench] direct RCCL path unavailable ({e}); using torch.distributed', file=sys.stderr)
-            rccl = None
+        # every rank or none (a rank that cannot build its private communicator must not leave the others inside a collective): any
+        # set-up problem on any rank drops the whole job to torch.distributed's all-gather, and the `comm` block says why
+        from monorun_amd.parallel import agreed_rccl_all_gather
+        rccl, rccl_why = agreed_rccl_all_gather(dev)
+        if rccl is None:
+            print(f'[bench] rank {rank}: direct RCCL path unavailable ({rccl_why}); the job uses torch.distributed\'s all-gather', file=sys.stderr)
     # Launches in flight.  One launch of 1024 objects lasts as long as its slowest object, and launches on one stream serialise;
     # the product's PnPPipeline issues the steps round-robin on L streams so that the next batches fill the SIMDs a launch's tail
     # leaves idle.  Every step is still ONE full config-2 launch over its own batch into its own result buffers.
@@ -533,7 +533,8 @@ def run(args):
                 'nranks': dist.get_world_size(), 'bytes_per_rank': row, 'steps_per_collective': 1}
     elif use_dist:
         comm = {'backend': 'rccl (private communicator, ncclAllGather on a side stream behind the step\'s completion event, overlapped with the following steps)' if rccl is not None
-                else 'rccl via torch.distributed (nccl backend) all_gather_into_tensor',
+                else ('rccl via torch.distributed (nccl backend) all_gather_into_tensor' +
+                      (f' — FALLBACK: the private RCCL communicator could not be set up on every rank ({rccl_why}); ~45 us of host time per collective instead of ~5' if rccl_why else '')),
                 'nranks': rccl.nranks() if rccl is not None else dist.get_world_size(),
                 'bytes_per_rank': main_loop.G * row, 'steps_per_collective': main_loop.G, 'result_slots': S}
         if rccl is not None:

@@ -108,8 +108,10 @@ class _NcclUniqueId(ctypes.Structure):
 
 
 def _rccl():
-    path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-    lib = ctypes.CDLL(path if os.path.exists(path) else 'librccl.so')
+    # the RCCL build torch itself links (so that one process holds one RCCL), else the system's; MR_RCCL_LIBRARY overrides (tests use it
+    # to provoke the set-up failure whose fallback `agreed_rccl_all_gather` handles)
+    path = os.environ.get('MR_RCCL_LIBRARY') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+    lib = ctypes.CDLL(path if (os.environ.get('MR_RCCL_LIBRARY') or os.path.exists(path)) else 'librccl.so')
     lib.ncclGetUniqueId.restype = ctypes.c_int
     lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
     lib.ncclCommInitRank.restype = ctypes.c_int
@@ -123,6 +125,35 @@ def _rccl():
     lib.ncclGetErrorString.restype = ctypes.c_char_p
     lib.ncclGetErrorString.argtypes = [ctypes.c_int]
     return lib
+
+
+def agreed_rccl_all_gather(device, group=None):
+    """``RcclAllGather(device)`` on EVERY rank or on none: returns (exchange | None, reason | None).
+
+    The private communicator is an optimisation (its collective costs ~5 us of host time against ~45 us through c10d); a rank that
+    cannot set it up — library not found, a symbol missing, ncclCommInitRank refusing — must not leave the others waiting inside a
+    collective it will never join.  Every rank therefore reports its own outcome, the job takes the minimum, and if any rank failed
+    all of them drop to ``torch.distributed``'s all-gather (the caller says so in its output).  What this does NOT cover: a bootstrap
+    that hangs instead of failing (then the job's own timeout applies).  Failure modes handled: see DESIGN.md section 8."""
+    ag, why = None, None
+    try:
+        ag = RcclAllGather(device, group)
+        if ag.nranks() != dist.get_world_size(group):
+            why = f'ncclCommCount reports {ag.nranks()} ranks, the job has {dist.get_world_size(group)}'
+    except Exception as e:                                       # noqa: BLE001 — any set-up problem
+        why = f'{type(e).__name__}: {e}'
+    ok = torch.tensor([0 if why else 1], dtype=torch.int32, device=device if dist.get_backend(group) == 'nccl' else 'cpu')
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return ag, None
+    if ag is not None and why is None:
+        why = 'another rank could not set up its private RCCL communicator'
+    if ag is not None:
+        try:
+            ag.close()
+        except Exception:                                        # noqa: BLE001
+            pass
+    return None, why
 
 
 class RcclAllGather:

@@ -62,7 +62,7 @@ def load_batch(dumps_dir, ids, infos, img_shape):
     """The objects of a batch of images as ONE list (what the detector hands to the pose stage, monorun_roi_head.py:509-534), with
     per-object camera / image shape / flip flag so that images of different cameras share a launch.  numpy arrays on the host."""
     cols = dict(all_pred=[], labels=[], dim=[], dim_var=[], rois=[], scores=[], scores_2d=[], bboxes=[], K=[], hw=[], flip=[], img=[])
-    has_var = True
+    with_var = []
     for k, (iid, info) in enumerate(zip(ids, infos)):
         d = np.load(os.path.join(dumps_dir, iid + '.npz'))
         n = len(d['labels'])
@@ -72,16 +72,21 @@ def load_batch(dumps_dir, ids, infos, img_shape):
         hw = np.asarray(d['img_shape'], np.float32).reshape(-1)[:2] if 'img_shape' in d else np.asarray(img_shape, np.float32)
         r = np.asarray(d['rois'], np.float32).reshape(n, -1)
         cols['all_pred'].append(np.asarray(d['all_pred'])); cols['labels'].append(np.asarray(d['labels'], np.int64)); cols['dim'].append(np.asarray(d['dim'], np.float32))
-        has_var = has_var and 'dim_var' in d
-        if has_var:
+        with_var.append('dim_var' in d)
+        if with_var[-1]:
             cols['dim_var'].append(np.asarray(d['dim_var'], np.float32))
         cols['rois'].append(r[:, 1:5] if r.shape[1] == 5 else r)
         cols['scores'].append(np.asarray(d['scores_ref'] if 'scores_ref' in d else d['scores'], np.float32).reshape(n))
         cols['scores_2d'].append(np.asarray(d['scores'], np.float32).reshape(n)); cols['bboxes'].append(np.asarray(d['bboxes'], np.float32).reshape(n, 4))
         cols['K'].append(np.broadcast_to(K, (n, 3, 3))); cols['hw'].append(np.broadcast_to(hw, (n, 2)))
         cols['flip'].append(np.full(n, bool(d['flip']) if 'flip' in d else False)); cols['img'].append(np.full(n, k, np.int64))
+    if any(with_var) and not all(with_var):
+        # one launch decodes every object of the batch with OR without the dimension variance: a mixed batch would silently change
+        # dimensions_var for the images that carry it
+        raise ValueError('load_batch: the dumps of one batch disagree on dim_var (' + ', '.join(i for i, w in zip(ids, with_var) if not w)[:200] +
+                         ' lack it): dump them with the same head configuration, or use --images-per-batch 1')
     out = {k: (np.concatenate(v) if v else None) for k, v in cols.items() if k != 'dim_var'}
-    out['dim_var'] = np.concatenate(cols['dim_var']) if has_var and cols['dim_var'] else None
+    out['dim_var'] = np.concatenate(cols['dim_var']) if cols['dim_var'] else None
     return out
 
 
@@ -102,7 +107,7 @@ def run(a, pose_fn=None, backend='nccl', dev=None, evaluate_fn=None):
     solves its shard, and ONE all-gather of the packed per-object rows (pose, covariance, validity, decoded dimensions: 100 bytes
     per object) per batch gives every rank the whole batch — BASELINE config 4's "proposals sharded across the GPUs with an RCCL
     all-gather of poses".  Returns (ap_dict, text) on rank 0, (None, None) elsewhere."""
-    from monorun_amd.parallel import PackedResults, RcclAllGather, sharded_pnp
+    from monorun_amd.parallel import PackedResults, agreed_rccl_all_gather, sharded_pnp
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     if dev is None:
         dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))) if backend == 'nccl' else torch.device('cpu')
@@ -124,17 +129,22 @@ def run(a, pose_fn=None, backend='nccl', dev=None, evaluate_fn=None):
         head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False,
                                                initialiser=a.initialiser)).to(dev)
         pose_fn = lambda ob, lo, hi: pose_objects(head, ob, lo, hi, dev)
-    exchange = RcclAllGather(dev) if (world > 1 and backend == 'nccl') else None      # private communicator, collectives on a side stream
+    # private communicator, collectives on a side stream — on every rank or on none (any set-up problem: torch.distributed's all-gather)
+    exchange, why = agreed_rccl_all_gather(dev) if (world > 1 and backend == 'nccl') else (None, None)
+    if why and rank == 0:
+        print(f'kitti_val: private RCCL communicator unavailable ({why}); using torch.distributed all_gather_into_tensor', file=sys.stderr)
     infos = []
     for iid in ids:
         calib = ev.open_calib_file(os.path.join(a.calib, iid + '.txt'), 2)
         label = ev.open_label_file(os.path.join(a.labels, iid + '.txt')) if a.labels else None
         infos.append(ev.parse_ann_info(label, calib, CLASSES))
-    results, n_coll = {}, 0
+    results, n_coll, t_read = {}, 0, 0.0
     t0 = time.perf_counter()
     for i0 in range(0, len(ids), a.images_per_batch):
         i1 = min(i0 + a.images_per_batch, len(ids))
-        ob = load_batch(a.dumps, ids[i0:i1], infos[i0:i1], tuple(a.img_shape))
+        tr0 = time.perf_counter()
+        ob = load_batch(a.dumps, ids[i0:i1], infos[i0:i1], tuple(a.img_shape))      # every rank reads the batch's dumps (page-cached after the first): not pose-stage time
+        t_read += time.perf_counter() - tr0
         n = 0 if ob['labels'] is None else len(ob['labels'])
 
         def solve(lo, hi, packed):
@@ -163,7 +173,7 @@ def run(a, pose_fn=None, backend='nccl', dev=None, evaluate_fn=None):
                 results[i0 + k] = dict(bbox_results=[b2[ob['labels'][sel] == c] for c in range(len(CLASSES))], bbox_3d_results=b3)
     if dev.type == 'cuda':
         torch.cuda.synchronize()
-    t_pose = time.perf_counter() - t0
+    t_pose = time.perf_counter() - t0 - t_read
     ap_dict = text = None
     if rank == 0:
         out = a.out or tempfile.mkdtemp(prefix='mr_kitti_results_')
@@ -172,7 +182,7 @@ def run(a, pose_fn=None, backend='nccl', dev=None, evaluate_fn=None):
         print(text)
         n_obj = sum(len(r['bbox_3d_results'][c]) for r in results.values() for c in range(len(CLASSES)))
         print(f'{len(ids)} images, {n_obj} objects, initialiser {a.initialiser!r}: pose stage {t_pose:.2f} s ({world} rank(s), objects sharded, {n_coll} packed '
-              f'all-gather(s) of 100-byte rows{" over a private RCCL communicator" if exchange is not None else ""}; incl. file reads), '
+              f'all-gather(s) of 100-byte rows{" over a private RCCL communicator" if exchange is not None else ""}; reading the dumps took {t_read:.2f} s more), '
               f'formatting + result files + evaluation {time.perf_counter() - t0:.2f} s; result files in {out}/data')
     if exchange is not None:
         exchange.close()
