@@ -1,0 +1,3 @@
+python -m pytest tests/test_gpu_epnp.py -x -q -m gpu 2>&1 | tail -3
+bash tools/epnp_valu_per_launch.sh | tail -10
+GROUP=3 DEPTHS=1,4 python tools/gpu_epnp_inflight.py 2>&1 | grep -v amdgpu.ids
