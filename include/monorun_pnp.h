@@ -152,10 +152,11 @@ int mr_pnp_uncert_batched(
  * reused once the work queued on `stream` has passed it (17 MB per 1024 objects).  workspace = NULL: the library takes it from a
  * stream-ordered memory pool OF ITS OWN (one per device, created on first use, freed blocks kept for the next call: hipMallocFromPoolAsync /
  * hipFreeAsync on `stream`); the process's default pool and its attributes are not touched.  Pass a workspace for steady-state use.
- * VERSION-DEPENDENT DECISIONS (oracle/epnp.inc): with thresholds, an object with exactly FOUR candidates (only possible when P = 4) gets
- * what OpenCV returns after its one P3P step — EPnP on the four points, all four inliers — without P3P's own solvability test (not
- * restated); P >= 5 is unaffected (fewer than five istd candidates fall back to all P points).  MR_EPNP_REFIT_F32 selects round 3's
- * float32 re-fit.
+ * VERSION-DEPENDENT DECISIONS (oracle/epnp.inc): with thresholds, an object with exactly FOUR (only possible when P = 4) or FIVE candidates
+ * deliberately differs from OpenCV >= 3.3 as published, whose solvePnPRansac returns early when model_points == npoints (P3P's pose for
+ * four points, float32 EPnP for five): here both get EPnP on the candidates with the float64 normalisation of every re-fit, all of them
+ * inliers; P3P and its solvability test are not restated.  P >= 6 candidates (every shipped configuration) is unaffected.
+ * MR_EPNP_REFIT_F32 selects round 3's float32 re-fit.
  */
 int mr_epnp_ransac_batched(
     const void *x2d, const int64_t *x2d_strides, const void *istd, const int64_t *istd_strides,

@@ -400,6 +400,38 @@ def test_adversarial_inputs_terminate_and_match_oracle_validity(dev, orc):
             assert np.array_equal(valid, ref[0]), (trial, mode, wpo)
 
 
+def test_wave_counts_give_bitwise_equal_results(dev):
+    """the one- and two-wave instantiations evaluate the LM point loop and the covariance pass first as if no clamp of the
+    functor were active (and redo a lane's sums with the full form when one was); the four-wave kernel has the full form only.  Where
+    no clamp is active both forms must give the SAME bits — a property that rests on the compiler contracting the two forms alike, so
+    it is pinned here: validity, poses, covariances and masks of 1, 2, 4 and 8 waves per object are bitwise equal, the LM's iteration
+    counts and exit reasons identical, on ordinary objects, on objects whose projections leave the u / v range (clamps active) and
+    for the from-init (EXT) launch.  (The final trust-region radius and cost are float32 roundings of quantities that depend on the
+    summation order over the waves through the step-quality ratio: equal to 1e-6, one float32 ulp apart on 1 of 512 objects.)"""
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device, epnp_ransac_device, pnp_uncert_from_init_device
+    b = syn.make_batch(B=512, seed=77)
+    x2d, istd, x3d, K, ur, vr, thr = [_dv(a, dev) for a in syn.pnp_boundary(b, planar=True)]
+    tight_u = torch.tensor([[300.0, 900.0]], device=dev); tight_v = torch.tensor([[120.0, 260.0]], device=dev)      # many points get clamped
+
+    def same(a, r, what):
+        valid, pose, cov, tr, mask, diag = a
+        assert torch.equal(valid, r[0]) and torch.equal(pose, r[1]) and torch.equal(cov, r[2]) and torch.equal(mask, r[4]), what
+        assert torch.equal(diag[:, [0, 2, 3]], r[5][:, [0, 2, 3]]), what
+        torch.testing.assert_close(tr, r[3], rtol=1e-6, atol=0); torch.testing.assert_close(diag[:, 1], r[5][:, 1], rtol=1e-6, atol=0)
+    for rng_u, rng_v in ((ur, vr), (tight_u, tight_v)):
+        outs = {w: pnp_uncert_device(x2d, istd, x3d, K, rng_u, rng_v, 0.5, 0.6, thr, True, flags=w << 8, with_diag=True) for w in (1, 2, 4, 8)}
+        torch.cuda.synchronize()
+        for w in (1, 2, 8):
+            same(outs[w], outs[4], f'{w} waves per object differ from 4')
+        assert int(outs[4][0].sum()) > 400
+    ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
+    for rng_u, rng_v in ((ur, vr), (tight_u, tight_v)):
+        outs = {w: pnp_uncert_from_init_device(x2d, istd, x3d, K, rng_u, rng_v, ini, im, iv, z_min=0.5, inlier_opt_only=True, flags=w << 8, with_diag=True) for w in (1, 2, 4)}
+        torch.cuda.synchronize()
+        for w in (1, 2):
+            same(outs[w], outs[4], f'from-init launch: {w} waves per object differ from 4')
+
+
 def test_hip_kernel_against_the_reference_initialiser_restated(dev, orc):
     """R5: the explicit FAST MODE (initialiser='k0', the one-launch kernel; not the default since round 5) against the reference's flow with its OWN initialiser restated (EPnP inside
     OpenCV's RANSAC loop, oracle/epnp.inc) on a config-2 batch, compared after the LM: same validity, the same inlier set
