@@ -473,7 +473,8 @@ def run(args):
     # slower in a fresh process than after ~40 ms of launches (profiles/r04_closing_schedule_experiment.txt).  A serving process is
     # never in that state, so MR_BENCH_PREWARM_LAUNCHES (default 2048, ~ 60 ms) launches of the hot path are issued through the same
     # pipeline first; the W warm-up steps of the contract follow as before.
-    prewarm_n = int(os.environ.get('MR_BENCH_PREWARM_LAUNCHES', '2048'))
+    # (a FIXED count per flow and workload — every rank issues the same launches —: ~0.1 s of them)
+    prewarm_n = int(os.environ.get('MR_BENCH_PREWARM_LAUNCHES', '64' if stress else ('768' if ref_flow else '2048')))
     prewarm = {'launches_asked': prewarm_n, 'launches': 0, 'ms': 0.0}
     if prewarm_n > 0:
         # the same K-step window first, as a just-started process sees it (reported beside `value`, never as `value`)
@@ -483,7 +484,6 @@ def run(args):
         # at most prewarm_n launches and about 0.1 s of them (a stress-shape launch lasts ~ 1 ms), no collective in here, through the
         # pipeline of the timed loop
         pp = pipe_of(L_ASKED)
-        prewarm_n = min(prewarm_n, max(S, int(0.1 / max(cold / max(args.steps, 1), 1e-9))))
         t0 = time.perf_counter()
         for blk in range((prewarm_n + S - 1) // S):
             for sl in range(S):
@@ -707,6 +707,7 @@ def run(args):
                          'note': ('formally HBM-bound (each launch streams the tile once); in practice VALU issue bound: ~49 M fp64-heavy wave-instructions per call '
                                   '(profiles/r05_epnp_valu_per_launch.txt), the stages are latency chains (DESIGN.md section 3)' if ref_flow else
                                   'formally HBM-bound (read-once streaming); in practice VALU/latency-bound: the tile is LDS-resident across all LM iterations (DESIGN.md)')},
+            'value_cold': prewarm.get('window_before', {}).get('value'),      # the same window in a just-started process (before the reported pre-conditioning): compare THIS with rounds 1-3
             'valid_fraction': valid_frac,
             'outputs_verified': outputs_ok,
             'secondary_throughput': extra,
