@@ -60,9 +60,11 @@ extern "C" {
 #define MR_COV_NONE           0x8     /* do not compute the pose covariance (cov left untouched) */
 #define MR_COV_CERES          0x10    /* covariance with the solver's (Ceres/autodiff) Jacobian instead of the
                                          torch Jacobian of jacobian.py (what `pnp_uncert`'s result_cov is) */
-#define MR_ANY_ORDER          0x20    /* mr_pnp_uncert_batched ONLY (every other entry point ignores the bit): the launch may start before earlier
-                                         work on the same stream has finished (hipExtAnyOrderLaunch: no barrier bit on the dispatch); the caller
-                                         orders consumers with events.  Experimental */
+#define MR_ANY_ORDER          0x20    /* mr_pnp_uncert_batched and mr_pnp_uncert_from_init_batched (every other entry point ignores the bit): the
+                                         launch may start before earlier work on the same stream has finished (hipExtAnyOrderLaunch: no barrier
+                                         bit on the dispatch: it starts once the launch in front of it has STARTED); the caller orders producers
+                                         and consumers.  monorun_amd.PnPEpnpGroupLaunch uses it for the LM launches of the second and later calls
+                                         of a launch set: the first one (ordinary) waits for the set's initialiser, the others run beside it */
 #define MR_WAVES_SHIFT        8       /* bits 8..11: wavefronts cooperating on one object (0 = auto, 1,2,4,8) */
 #define MR_WAVES_MASK         (0xF << MR_WAVES_SHIFT)
 #define MR_LM_MAXIT_SHIFT      16      /* bits 16..21: Ceres' max_num_iterations for the LM (0 = the default, 50; 1..63) */

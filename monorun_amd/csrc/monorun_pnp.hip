@@ -880,7 +880,11 @@ int launch_ext(const PnpArgs &a, hipStream_t st) {
             if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
         }
     }
-    hipLaunchKernelGGL((pnp_uncert_kernel<T, WPO, true>), dim3(a.B), dim3(64 * WPO), lds, st, a);
+    if (a.flags & MR_ANY_ORDER)      // no barrier bit on the dispatch packet: the launch starts once the launch in front of it has STARTED (the LM launches
+        // of the calls of one launch set: the first waits for the set's initialiser launches, the others run beside it — PnPEpnpGroupLaunch)
+        hipExtLaunchKernelGGL((pnp_uncert_kernel<T, WPO, true>), dim3(a.B), dim3(64 * WPO), (uint32_t)lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a);
+    else
+        hipLaunchKernelGGL((pnp_uncert_kernel<T, WPO, true>), dim3(a.B), dim3(64 * WPO), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MR_OK;
 }

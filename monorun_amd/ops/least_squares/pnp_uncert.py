@@ -282,7 +282,7 @@ class PnPEpnpGroupLaunch:
     initialiser's stages are latency chains that fill a fraction of the chip, so a ``PnPPipeline`` of depth 4 that is fed groups
     of two keeps EIGHT calls' stages in flight (measured on MI355X, reference flow, 1024-object calls: DESIGN.md section 3)."""
 
-    def __init__(self, launches, work=None):
+    def __init__(self, launches, work=None, lm_side_by_side=True):
         """work: a uint8 workspace of at least mr_epnp_workspace_bytes(len(launches) * B, P) bytes (shared between groups that only
         ever run on one stream), or None to allocate one."""
         self.members = list(launches)
@@ -306,6 +306,12 @@ class PnPEpnpGroupLaunch:
         assert self.work.dtype == torch.uint8 and self.work.numel() >= need and self.work.data_ptr() % 256 == 0
         self.args = [n, x2d, ai[1], istd, ai[3], x3d, ai[5], ai[6], cam, ai[8], thr, f.B, P, ai[12], ai[13], ai[14],
                      ipose, imask, ivalid, idiag, self.work.data_ptr(), self.work.numel()]
+        self.lm_side_by_side = lm_side_by_side
+        self._lm_any = []
+        for m in self.members:                             # args_lm with MR_ANY_ORDER in its flags (argument 19 of mr_pnp_uncert_from_init_batched)
+            a = list(m.args_lm)
+            a[19] = int(a[19]) | _lib.MR_ANY_ORDER
+            self._lm_any.append(a)
 
     def run(self, stream=None):
         if self.B == 0:
@@ -313,10 +319,13 @@ class PnPEpnpGroupLaunch:
         st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
         with torch.cuda.device(self.dev):
             code = self.lib.mr_epnp_ransac_grouped(*self.args, st)
-            for m in self.members:
+            for k, m in enumerate(self.members):
                 if code:
                     break
-                code = self.lib.mr_pnp_uncert_from_init_batched(*m.args_lm, st)
+                # the first call's LM launch waits for the set's initialiser launches (stream order); the others carry MR_ANY_ORDER:
+                # they start as soon as the one in front of them has started, i.e. the set's LM launches run side by side instead
+                # of each waiting for the slowest object of the one before
+                code = self.lib.mr_pnp_uncert_from_init_batched(*(m.args_lm if (k == 0 or not self.lm_side_by_side) else self._lm_any[k]), st)
         if code:
             _lib.check(code)
 
