@@ -1033,7 +1033,7 @@ def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=4):
     385 MB > the Infinity Cache; four = the depth of the pipeline the headline runs with) to poses: K2 alone (`noc_decode_kernel`, the one HBM-bound kernel of the path), K2 + PnP as two
     launches, and the fused one-launch kernel; each with its algorithmic bytes against the 8 TB/s HBM roofline."""
     from monorun_amd.pose_head import NocDecodeLaunch, PoseFromHeadLaunch, UncertPropPnPOptimizer, _planar_view, _clip_ranges
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False, initialiser='k0')).to(dev)      # the fast mode's one-launch head -> pose path
     k2s, fus, pnps = [], [], []
     for i in range(n_batches):
         b = syn.make_batch(B=B_PER_GPU, hw=HW, seed=SEED + 7919 * i)
@@ -1106,7 +1106,7 @@ def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):
     from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
     sub = {k: (v[:n_obj] if isinstance(v, np.ndarray) and v.shape[:1] == (batch0['labels'].shape[0],) else v) for k, v in batch0.items()}
     all_pred, dim = syn.encode_head_outputs(sub, seed=SEED)
-    head = UncertPropPnPOptimizer().to(dev)
+    head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False, initialiser='k0')).to(dev)      # the fast mode's one-launch head -> pose path
     ap, lab, dm, rois = torch.from_numpy(all_pred).to(dev), torch.from_numpy(sub['labels']).to(dev), torch.from_numpy(dim).to(dev), torch.from_numpy(sub['rois']).to(dev)
     K = torch.from_numpy(sub['K']).to(dev)
     out = {}
