@@ -202,6 +202,20 @@ int mr_pnp_uncert_from_init_batched(
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream);
 
 /*
+ * The same launch over the objects of SEVERAL calls (1 <= ncalls <= 4; the companion of mr_epnp_ransac_grouped): arrays of ncalls device
+ * pointers (read on the host) for everything a caller owns; B objects per call; P, strides, in_dtype, cam_batch, range_batch, z_min and
+ * the flags are common (inlier_mask and diag: all NULL or none).  Results are those of ncalls calls of mr_pnp_uncert_from_init_batched,
+ * bit for bit.  One launch lasts as long as its slowest object: carried by one launch, the calls of a launch set pay that tail once.
+ */
+int mr_pnp_uncert_from_init_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *u_range, const float *const *v_range, int range_batch,
+    const double *const *init_pose, const uint8_t *const *init_mask, const uint8_t *const *init_valid, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream);
+
+/*
  * The reference's eigenvalue rule for ill-conditioned Hessians (pnp_uncert.py:77-85), applied per object to the outputs of
  * mr_pnp_uncert_batched / mr_pnp_uncert_from_init_batched: an object stays valid only if lambda_min(h) > max(1e-6 * lambda_max(h), 0)
  * (evaluated on cov = h^-1, whose eigenvalues are the reciprocals); otherwise valid[b] = 0 and cov[b] = identity.  The fused kernel

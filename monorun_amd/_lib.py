@@ -32,7 +32,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp6_kernel.inc"), os.path.join(_HERE, "csrc", "hessian_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_eig_low4.inc"), os.path.join(_HERE, "csrc", "epnp_stages.inc"), os.path.join(_HERE, "csrc", "kitti_eval_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
+    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_kernel_body.inc"), os.path.join(_HERE, "csrc", "pnp6_kernel.inc"), os.path.join(_HERE, "csrc", "hessian_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_eig_low4.inc"), os.path.join(_HERE, "csrc", "epnp_stages.inc"), os.path.join(_HERE, "csrc", "kitti_eval_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -86,6 +86,9 @@ def load():
     lib.mr_pnp_uncert_from_init_batched.restype = i32
     lib.mr_pnp_uncert_from_init_batched.argtypes = [vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, f32, i32, i32,
                                                     vp, vp, vp, vp, vp, vp, vp]
+    lib.mr_pnp_uncert_from_init_grouped.restype = i32
+    lib.mr_pnp_uncert_from_init_grouped.argtypes = [i32, vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, f32, i32, i32,
+                                                    vp, vp, vp, vp, vp, vp, vp]
     lib.mr_cov_symeig_rule.restype = i32
     lib.mr_cov_symeig_rule.argtypes = [vp, vp, i32, vp, vp]
     lib.mr_pnp_exact_hessian_batched.restype = i32
@@ -137,5 +140,5 @@ def check(code):
 
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_spin', 'mr_pick_waves', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
-                    'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_ransac_grouped', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
+                    'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_ransac_grouped', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_pnp_uncert_from_init_grouped', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
                     'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

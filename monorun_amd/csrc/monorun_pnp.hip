@@ -578,6 +578,17 @@ struct PnpArgs {
     PairwisePlan plan;
     const uint8_t *init_mask, *init_valid;    // EXT launches only (appended: the offsets of everything above are what the tuned kernels read)
 };
+// EXT launches over the objects of several calls (mr_pnp_uncert_from_init_grouped; a SECOND kernel argument of a kernel of its own, so that
+// the argument block — and with it the code — of every other instantiation stays what it was): object b belongs to call b / group_B, whose
+// pointers — biased on the host so that the GLOBAL object index addresses them — replace PnpArgs'
+struct PnpCallTable {
+    int ncalls, group_B;
+    struct CallPtrs {
+        const void *x2d, *istd, *x3d, *K, *ur, *vr;
+        const double *init_pose; const uint8_t *init_mask, *init_valid;
+        uint8_t *valid; float *pose, *cov, *tr; uint8_t *mask; float *diag;
+    } call[4];
+};
 
 #include "pnp_kernel.inc"
 #include "pnp6_kernel.inc"
@@ -867,9 +878,24 @@ int launch(const PnpArgs &a, hipStream_t st) {
 }
 
 template <typename T, int WPO>
-int launch_ext(const PnpArgs &a, hipStream_t st) {
+int launch_ext(const PnpArgs &a, hipStream_t st, const PnpCallTable *tbl = nullptr) {
     const size_t lds = lds_bytes(a, WPO);
     if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
+    if (tbl) {                              // the objects of several calls: the kernel that takes the call table as a second argument
+        if (lds > 48 * 1024) {
+            static std::mutex mu; static size_t granted[kMaxDevices] = {};
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            std::lock_guard<std::mutex> lk(mu);
+            if (dev < 0 || dev >= kMaxDevices || lds > granted[dev]) {
+                HIP_TRY(hipFuncSetAttribute((const void *)pnp_uncert_group_kernel<T, WPO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (dev >= 0 && dev < kMaxDevices) granted[dev] = lds;
+            }
+        }
+        hipLaunchKernelGGL((pnp_uncert_group_kernel<T, WPO>), dim3(a.B), dim3(64 * WPO), lds, st, a, *tbl);
+        HIP_TRY(hipGetLastError());
+        return MR_OK;
+    }
     if (lds > 48 * 1024) {
         static std::mutex mu; static size_t granted[kMaxDevices] = {};
         int dev = 0;
@@ -890,7 +916,7 @@ int launch_ext(const PnpArgs &a, hipStream_t st) {
 }
 
 template <typename T>
-int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
+int launch_wpo(PnpArgs &a, int wpo, hipStream_t st, const PnpCallTable *tbl = nullptr) {
     a.elem_size = (int)sizeof(T);
     a.vec = (!a.from_head && a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;      // channel-planar rows: coalesced per-point loads
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
@@ -900,12 +926,13 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st) {
         if (wpo < 2) wpo = 2;
         if (wpo == 3) wpo = 4;
         switch (wpo) {
-            case 2: return launch_ext<T, 2>(a, st);
-            case 4: return launch_ext<T, 4>(a, st);
-            case 8: return launch_ext<T, 8>(a, st);
+            case 2: return launch_ext<T, 2>(a, st, tbl);
+            case 4: return launch_ext<T, 4>(a, st, tbl);
+            case 8: return launch_ext<T, 8>(a, st, tbl);
             default: return MR_ERR_BAD_ARGUMENT;
         }
     }
+    if (tbl) return MR_ERR_BAD_ARGUMENT;
     switch (wpo) {
         case 1: return launch<T, 1>(a, st);
         case 2: return launch<T, 2>(a, st);
@@ -1107,7 +1134,8 @@ static int pnp_uncert_launch(
     const float *cam_mats, int cam_batch, const float *u_range, const float *v_range, int range_batch,
     const float *ransac_thr, const double *init_pose, const uint8_t *init_mask, const uint8_t *init_valid, int B, int P,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
-    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream) {
+    uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream,
+    int ncalls = 1, const PnpCallTable::CallPtrs *calls = nullptr) {
     if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range ||
@@ -1130,12 +1158,20 @@ static int pnp_uncert_launch(
     if (mm == MR_MEAN_PAIRWISE && !(flags & MR_NO_ISTD_MASK) && !init_mask) {
         if (!build_plan(a.plan, P)) return MR_ERR_UNSUPPORTED;
     }
-    const int wpo = widen_for_large_tiles(pick_wpo(B, P, flags), a, flags, in_dtype);
+    PnpCallTable tbl;
+    memset(&tbl, 0, sizeof tbl);
+    tbl.ncalls = 1; tbl.group_B = B;
+    if (ncalls > 1) {                                   // a launch over the objects of several calls (EXT only): mr_pnp_uncert_from_init_grouped
+        tbl.ncalls = ncalls; a.B = B * ncalls;
+        for (int c = 0; c < ncalls; ++c) tbl.call[c] = calls[c];
+    }
+    const int wpo = widen_for_large_tiles(pick_wpo(a.B, P, flags), a, flags, in_dtype);
     hipStream_t st = (hipStream_t)stream;
+    const PnpCallTable *tp = ncalls > 1 ? &tbl : nullptr;
     switch (in_dtype) {
-        case MR_F32: return launch_wpo<float>(a, wpo, st);
-        case MR_F16: return launch_wpo<__half>(a, wpo, st);
-        case MR_F64: return launch_wpo<double>(a, wpo, st);
+        case MR_F32: return launch_wpo<float>(a, wpo, st, tp);
+        case MR_F16: return launch_wpo<__half>(a, wpo, st, tp);
+        case MR_F64: return launch_wpo<double>(a, wpo, st, tp);
         default: return MR_ERR_UNSUPPORTED;
     }
 }
@@ -1163,6 +1199,41 @@ int mr_pnp_uncert_from_init_batched(
     return pnp_uncert_launch(x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, u_range, v_range, range_batch,
                              nullptr, init_pose, init_mask, init_valid, B, P, z_min, 0.0f, inlier_opt_only, flags,
                              valid, pose, cov, tr_radius, inlier_mask, diag, stream);
+}
+
+int mr_pnp_uncert_from_init_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *u_range, const float *const *v_range, int range_batch,
+    const double *const *init_pose, const uint8_t *const *init_mask, const uint8_t *const *init_valid, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream) {
+    if (ncalls < 1 || ncalls > 4 || B < 0) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !init_pose || !init_mask || !init_valid ||
+        !valid || !pose || !tr_radius || !cov) return MR_ERR_BAD_ARGUMENT;
+    const bool with_mask = inlier_mask && inlier_mask[0], with_diag = diag && diag[0];
+    const size_t esize = in_dtype == MR_F64 ? 8 : (in_dtype == MR_F32 ? 4 : 2);
+    const long long ks = (cam_batch == 1) ? 0 : 9, rs = (range_batch == 1) ? 0 : 2;
+    PnpCallTable::CallPtrs cp[4];
+    for (int c = 0; c < ncalls; ++c) {
+        if (!x2d[c] || !istd[c] || !x3d[c] || !cam_mats[c] || !u_range[c] || !v_range[c] || !init_pose[c] || !init_mask[c] || !init_valid[c] ||
+            !valid[c] || !pose[c] || !tr_radius[c] || (!cov[c] && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
+        if ((inlier_mask && inlier_mask[c] != nullptr) != with_mask || (diag && diag[c] != nullptr) != with_diag) return MR_ERR_BAD_ARGUMENT;      // all or none
+        // pointers biased so that the GLOBAL object index c * B + i addresses object i of call c
+        const long long o = (long long)c * B;
+        PnpCallTable::CallPtrs &q = cp[c];
+        q.x2d = (const char *)x2d[c] - o * x2d_strides[0] * (long long)esize;
+        q.istd = (const char *)istd[c] - o * istd_strides[0] * (long long)esize;
+        q.x3d = (const char *)x3d[c] - o * x3d_strides[0] * (long long)esize;
+        q.K = (const char *)cam_mats[c] - o * ks * 4; q.ur = (const char *)u_range[c] - o * rs * 4; q.vr = (const char *)v_range[c] - o * rs * 4;
+        q.init_pose = init_pose[c] - o * 4; q.init_mask = init_mask[c] - o * P; q.init_valid = init_valid[c] - o;
+        q.valid = valid[c] - o; q.pose = pose[c] - o * 4; q.cov = cov[c] ? cov[c] - o * 16 : nullptr; q.tr = tr_radius[c] - o;
+        q.mask = with_mask ? inlier_mask[c] - o * P : nullptr; q.diag = with_diag ? diag[c] - o * 4 : nullptr;
+    }
+    return pnp_uncert_launch(x2d[0], x2d_strides, istd[0], istd_strides, x3d[0], x3d_strides, in_dtype, cam_mats[0], cam_batch, u_range[0], v_range[0], range_batch,
+                             nullptr, init_pose[0], init_mask[0], init_valid[0], B, P, z_min, 0.0f, inlier_opt_only, flags,
+                             valid[0], pose[0], cov[0], tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp);
 }
 
 static int epnp_ransac_launch(

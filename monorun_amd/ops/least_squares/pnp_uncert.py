@@ -282,8 +282,11 @@ class PnPEpnpGroupLaunch:
     initialiser's stages are latency chains that fill a fraction of the chip, so a ``PnPPipeline`` of depth 4 that is fed groups
     of two keeps EIGHT calls' stages in flight (measured on MI355X, reference flow, 1024-object calls: DESIGN.md section 3)."""
 
-    def __init__(self, launches, work=None, lm_side_by_side=True):
-        """work: a uint8 workspace of at least mr_epnp_workspace_bytes(len(launches) * B, P) bytes (shared between groups that only
+    def __init__(self, launches, work=None, lm='grouped'):
+        """lm: how the members' LM + covariance launches are issued behind the set's initialiser — 'grouped' (default): ONE launch over the
+        objects of all members (``mr_pnp_uncert_from_init_grouped``: the set pays its slowest object once); 'side_by_side': one launch per
+        member, the second and later ones with MR_ANY_ORDER; 'serial': one per member in stream order.  Same results.
+        work: a uint8 workspace of at least mr_epnp_workspace_bytes(len(launches) * B, P) bytes (shared between groups that only
         ever run on one stream), or None to allocate one."""
         self.members = list(launches)
         n = len(self.members)
@@ -306,7 +309,18 @@ class PnPEpnpGroupLaunch:
         assert self.work.dtype == torch.uint8 and self.work.numel() >= need and self.work.data_ptr() % 256 == 0
         self.args = [n, x2d, ai[1], istd, ai[3], x3d, ai[5], ai[6], cam, ai[8], thr, f.B, P, ai[12], ai[13], ai[14],
                      ipose, imask, ivalid, idiag, self.work.data_ptr(), self.work.numel()]
-        self.lm_side_by_side = lm_side_by_side
+        if lm not in ('grouped', 'side_by_side', 'serial'):
+            raise ValueError("lm must be 'grouped', 'side_by_side' or 'serial'")
+        al = f.args_lm
+        lm_same = lambda m: (m.args_lm[11] == al[11] and m.args_lm[17:20] == al[17:20] and (m.args_lm[25] is None) == (al[25] is None))
+        if not all(lm_same(m) for m in self.members):
+            raise ValueError('the members of a group must share range batching, z_min, inlier_opt_only and flags')
+        self.lm = lm
+        larr = lambda k: (ctypes.c_void_p * n)(*[m.args_lm[k] for m in self.members])
+        self._lm_arrays = {k: larr(k) for k in (9, 10, 12, 13, 14, 20, 21, 22, 23, 24, 25)}
+        la = self._lm_arrays
+        self.args_lm = [n, x2d, al[1], istd, al[3], x3d, al[5], al[6], cam, al[8], la[9], la[10], al[11], la[12], la[13], la[14], f.B, P, al[17], al[18], al[19],
+                        la[20], la[21], la[22], la[23], la[24], la[25]]
         self._lm_any = []
         for m in self.members:                             # args_lm with MR_ANY_ORDER in its flags (argument 19 of mr_pnp_uncert_from_init_batched)
             a = list(m.args_lm)
@@ -319,13 +333,18 @@ class PnPEpnpGroupLaunch:
         st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
         with torch.cuda.device(self.dev):
             code = self.lib.mr_epnp_ransac_grouped(*self.args, st)
+            if not code and self.lm == 'grouped' and len(self.members) > 1:
+                code = self.lib.mr_pnp_uncert_from_init_grouped(*self.args_lm, st)
+                if code:
+                    _lib.check(code)
+                return
             for k, m in enumerate(self.members):
                 if code:
                     break
                 # the first call's LM launch waits for the set's initialiser launches (stream order); the others carry MR_ANY_ORDER:
                 # they start as soon as the one in front of them has started, i.e. the set's LM launches run side by side instead
                 # of each waiting for the slowest object of the one before
-                code = self.lib.mr_pnp_uncert_from_init_batched(*(m.args_lm if (k == 0 or not self.lm_side_by_side) else self._lm_any[k]), st)
+                code = self.lib.mr_pnp_uncert_from_init_batched(*(m.args_lm if (k == 0 or self.lm != 'side_by_side') else self._lm_any[k]), st)
         if code:
             _lib.check(code)
 

@@ -368,14 +368,15 @@ def test_grouped_calls_equal_the_calls_one_by_one(dev):
         return (torch.equal(l.valid, r.valid) and torch.equal(l.pose, r.pose) and torch.equal(l.cov, r.cov) and torch.equal(l.tr, r.tr) and torch.equal(l.mask, r.mask)
                 and torch.equal(l.init_pose, r.init_pose) and torch.equal(l.init_mask, r.init_mask) and torch.equal(l.init_valid, r.init_valid))
     for members, diag in (([0, 1], True), ([2, 3, 6], False), ([0, 1, 2, 3], False), ([4, 5], False), ([6], False)):
-        ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], with_diag=diag, **kw) for i in members]
-        g = PnPEpnpGroupLaunch(ls)
-        g.run(); g.run(); torch.cuda.synchronize()
-        for l, i in zip(ls, members):
-            assert same(l, refs[i]), (members, i)
-            assert int(l.valid.sum()) > 150
-            if diag:
-                assert torch.equal(l.init_diag, refs[i].init_diag) and torch.equal(l.diag, refs[i].diag)
+        for lm in ('grouped', 'side_by_side', 'serial'):            # one LM launch over the set (mr_pnp_uncert_from_init_grouped) / one per member
+            ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], with_diag=diag, **kw) for i in members]
+            g = PnPEpnpGroupLaunch(ls, lm=lm)
+            g.run(); g.run(); torch.cuda.synchronize()
+            for l, i in zip(ls, members):
+                assert same(l, refs[i]), (members, i, lm)
+                assert int(l.valid.sum()) > 150
+                if diag:
+                    assert torch.equal(l.init_diag, refs[i].init_diag) and torch.equal(l.diag, refs[i].diag)
     # groups in flight: three groups of two on a depth-3 pipeline, twice over
     ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], **kw) for i in (0, 1, 2, 3, 6, 0)]
     groups = [PnPEpnpGroupLaunch(ls[2 * k:2 * k + 2]) for k in range(3)]

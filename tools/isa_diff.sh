@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 REV=$1; FRAG=${2:-pnp_uncert_kernelIfLi4ELb0E}; NEWFRAG=${3:-$FRAG}      # third argument: the fragment in the CURRENT build when the mangled name changed
 T=$(mktemp -d)
 mkdir -p $T/old
-for f in monorun_pnp.hip pnp_kernel.inc pnp6_kernel.inc pnp_noc_kernel.inc kitti_eval_kernel.inc hessian_kernel.inc epnp_kernel.inc epnp_eig_lanes.inc epnp_eig_low4.inc epnp_stages.inc; do
+for f in monorun_pnp.hip pnp_kernel.inc pnp_kernel_body.inc pnp6_kernel.inc pnp_noc_kernel.inc kitti_eval_kernel.inc hessian_kernel.inc epnp_kernel.inc epnp_eig_lanes.inc epnp_eig_low4.inc epnp_stages.inc; do
     git -C $ROOT show $REV:monorun_amd/csrc/$f > $T/old/$f 2>/dev/null || true
 done
 git -C $ROOT show $REV:include/monorun_pnp.h > $T/old/monorun_pnp.h          # the old sources against the old header (prototypes change)
