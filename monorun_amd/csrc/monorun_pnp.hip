@@ -1286,12 +1286,12 @@ static int epnp_ransac_launch(
     hipStream_t st = (hipStream_t)stream;
     // hypotheses solved for every object before the replayed loop is consulted: MR_EPNP_FIRST_ROUND bits of `flags` (1..30), else the
     // environment variable MR_EPNP_FIRST_ROUND, else by the size of the launch set: 8 up to 2047 objects (one call at a time: the
-    // second round is a full latency chain, and 8 hypotheses make it idle in 85 % of config-2 batches), 4 beyond (several calls grouped
-    // or a large batch: the chip is busy, the hypotheses nobody needs are the cost — 8.35 -> 9.03 M solves/s with groups of three,
-    // profiles/r05_epnp_grouped_first_round.txt).  Changes the work, never a result.
+    // second round is a full latency chain, and 8 hypotheses make it idle in 85 % of config-2 batches), 3 beyond (several calls grouped
+    // or a large batch: the chip is busy, the hypotheses nobody needs are the cost — sets of three calls: 9.6 / 9.9 / 10.3 / 10.3 M solves/s
+    // with 6 / 4 / 3 / 2, profiles/r05_epnp_grouped_first_round.txt).  Changes the work, never a result.
     static const int first_env = [] { const char *e = getenv("MR_EPNP_FIRST_ROUND"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > 30 ? 30 : v); }();
     const int first_bits = (flags & MR_EPNP_FIRST_ROUND_MASK) >> MR_EPNP_FIRST_ROUND_SHIFT;
-    const int first_round = first_bits ? (first_bits > 30 ? 30 : first_bits) : (first_env ? first_env : ((long long)B * ncalls >= 2048 ? 4 : 8));
+    const int first_round = first_bits ? (first_bits > 30 ? 30 : first_bits) : (first_env ? first_env : ((long long)B * ncalls >= 2048 ? 3 : 8));
     switch (in_dtype) {
         case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, first_round, st);
         case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, first_round, st);
