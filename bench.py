@@ -593,6 +593,11 @@ def run(args):
     extra = {}
     if world == 1 and not args.no_secondary and not ref_flow:
         extra = secondary(args, torch, syn, PnPLaunch, dev, dev_batches, batch0, np_batch0, NB)
+    if ref_flow and world == 1 and not args.no_secondary and not stress:
+        try:
+            extra['head_to_pose_1024_reference_flow'] = head_to_pose_reference(torch, syn, dev)
+        except Exception as e:                                          # noqa: BLE001 — secondary figure
+            extra['head_to_pose_1024_reference_flow'] = {'error': repr(e)}
     # reference flow: how one call splits into the initialiser's launches and the LM launch (HIP events on the launch stream, every batch)
     split = None
     if ref_flow:
@@ -1026,6 +1031,36 @@ def graph_us_per_launch(torch, fns, reps=20):
 def roof_of(nbytes, us):
     ach = nbytes / (us * 1e-6) / 1e9
     return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': nbytes}
+
+
+def head_to_pose_reference(torch, syn, dev, n_batches=4):
+    """The whole post-NOC-head tail as the pipeline's head built from the REFERENCE's config dict runs it (monorun_roi_head.py:509-534): K2
+    decode -> the reference's initialiser -> LM -> calibration, prepared launches (PoseFromHeadLaunch) over 4 distinct resident head
+    outputs, one at a time and four in flight."""
+    from monorun_amd.pose_head import PoseFromHeadLaunch, UncertPropPnPOptimizer
+    from monorun_amd import PnPPipeline
+    head = UncertPropPnPOptimizer().to(dev)
+    ls = []
+    for i in range(n_batches):
+        b = syn.make_batch(B=B_PER_GPU, hw=HW, seed=SEED + 7919 * i)
+        all_pred, dim = syn.encode_head_outputs(b, seed=SEED + i)
+        ls.append(PoseFromHeadLaunch(head, torch.from_numpy(all_pred).to(dev), torch.from_numpy(b['labels']).to(dev), False, torch.from_numpy(dim).to(dev), None,
+                                     torch.from_numpy(b['rois']).to(dev), torch.from_numpy(b['K']).to(dev), (syn.IMG_H, syn.IMG_W)))
+    out = {'what': "PoseFromHeadLaunch of a head built from the reference's config dict: K2 decode + EPnP / RANSAC initialiser + LM + calibration, 1024 objects per call"}
+    for name, depth in (('one_call_at_a_time', 1), ('in_flight', 4)):
+        pipe = PnPPipeline(dev, depth=depth, record_events=False)
+        for i in range(2 * n_batches):
+            pipe.submit(ls[i % n_batches], slot=i % n_batches)
+        pipe.drain()
+        n = 48
+        t0 = time.perf_counter()
+        for i in range(n):
+            pipe.submit(ls[i % n_batches], slot=i % n_batches)
+        pipe.drain()
+        el = time.perf_counter() - t0
+        out[name] = {'value': B_PER_GPU * n / el, 'unit': 'solves/s', 'us_per_call': el / n * 1e6, 'launches_in_flight': pipe.depth}
+    out['valid_fraction'] = float(ls[0].out['ret_val'].float().mean().item())
+    return out
 
 
 def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=4):
