@@ -9,7 +9,7 @@ started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gp
 
 A "step" is one pass of the hot path over one synthetic batch that is already resident in HBM: ONE CALL of the op as the
 reference's config dict builds it — the reference's flow: istd mask -> cv2.solvePnPRansac(EPNP, 30 iterations) restated
-(seven launches) -> LM -> covariance (one launch), through the C ABI — over 1024 objects per GPU, plus — when N > 1 — the
+(six launches + its re-fit's pose candidates as the prologue of the next) -> LM -> covariance (one launch), through the C ABI — over 1024 objects per GPU, plus — when N > 1 — the
 single RCCL all-gather of the packed per-object results (north_star: "objects shard across the GPUs with an RCCL all-gather
 of poses").  `--flow k0` measures the explicit one-launch fast mode instead (rounds 1-4's `value`); the default line carries
 it under `k0_fast_mode`.  Weak scaling: every rank owns 1024 objects per step.  The steps
@@ -607,11 +607,12 @@ def run(args):
         torch.cuda.synchronize()
         for i, (a, b, c) in enumerate(ev3):
             l = launches_one[i % NB][0]
-            a.record(); lib_.mr_epnp_ransac_batched(*l.args_init, st_); b.record(); lib_.mr_pnp_uncert_from_init_batched(*l.args_lm, st_); c.record()
+            g1 = l._single                          # the launch set of one call the launch object runs (re-fit deferred into the LM launch)
+            a.record(); lib_.mr_epnp_ransac_grouped(*g1.args, st_); b.record(); lib_.mr_pnp_uncert_from_epnp_grouped(*g1.args_fused, st_); c.record()
         torch.cuda.synchronize()
         ini_ms = np.array([a.elapsed_time(b) for a, b, c in ev3[NB:]]); lm_ms = np.array([b.elapsed_time(c) for a, b, c in ev3[NB:]])
         split = {'initialiser_launches_ms': float(ini_ms.mean()), 'lm_launch_ms': float(lm_ms.mean()), 'lm_launch_ms_per_batch': [float(v) for v in lm_ms],
-                 'what': 'one call at a time, HIP events on the launch stream around the seven launches of mr_epnp_ransac_batched and around the LM launch, averaged over the batches'}
+                 'what': 'one call at a time, HIP events on the launch stream around the six launches of mr_epnp_ransac_grouped (MR_EPNP_DEFER_REFIT) and around the LM launch that carries the re-fit (mr_pnp_uncert_from_epnp_grouped), averaged over the batches'}
 
     if rank == 0:
         total = B_PER_GPU * world * args.steps
@@ -747,7 +748,7 @@ def run(args):
                                     what=f'the timed loop over {ss["steps"]} steps (whole rotations): the {args.steps}-step window of `value` carries the fill and drain of the {L}-deep pipeline')
         if ref_flow:
             one = per_s(variants['single_stream']) if 'single_stream' in variants else None
-            lm_name = f'pnp_uncert_kernel<{"__half" if stress else "float"}, {((fl_one >> 8) & 15) or ("auto" if stress else 4)}, true>'
+            lm_name = f'pnp_uncert_refit_kernel<{"__half" if stress else "float"}, {((fl_one >> 8) & 15) or ("auto" if stress else 4)}>'
             line['reference_flow'] = {
                 'what': "`value` IS this flow since round 5: cv2.solvePnPRansac(EPNP, 30 iterations) restated on the GPU, then the LM + covariance — what PnPUncert built from the "
                         "reference's own config dict runs (INTEGRATION.md section 2); the one-launch K0 path is the explicit fast mode (`k0_fast_mode`)",
@@ -758,7 +759,7 @@ def run(args):
                 ach = BYTES_PER_SOLVE * B_PER_GPU / (split['lm_launch_ms'] * 1e-3) / 1e9
                 line['roofline']['dominant_kernel'] = {'kernel': lm_name, 'avg_launch_ms': split['lm_launch_ms'], 'achieved': ach, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                                                        'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU,
-                                                       'measured_on': 'HIP events on the launch stream around ISOLATED LM launches (one call at a time), every batch, in this run'}
+                                                       'measured_on': "HIP events on the launch stream around ISOLATED launches of the LM kernel (one call at a time; the launch also carries the initialiser's re-fit as its prologue), every batch, in this run"}
         if isinstance(extra.get('epnp_initialiser'), dict) and 'value' in extra['epnp_initialiser']:
             ep = extra['epnp_initialiser']
             line['reference_flow'] = {

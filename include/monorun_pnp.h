@@ -76,6 +76,10 @@ extern "C" {
 #define MR_EPNP_REFIT_F32   0x40      /* mr_epnp_ransac_batched: normalise the image points of solvePnPRansac's final re-fit in float32 (round 3's
                                          reading of OpenCV) instead of float64 (the published solvePnPRansac converts the inliers to CV_64F first;
                                          the default since round 4) — oracle/epnp.inc "version-dependent decisions" (i) */
+#define MR_EPNP_DEFER_REFIT 0x80      /* mr_epnp_ransac_batched / _grouped: stop before the last launch (the re-fit's pose candidates on the inliers):
+                                         init_mask is final, init_pose / init_valid / diag are NOT written — mr_pnp_uncert_from_epnp_grouped, given
+                                         the same (caller-owned, required) workspace on the same stream, does that work as the prologue of the LM
+                                         launch, where the object's correspondences are in LDS anyway, and writes them.  Same results, bit for bit. */
 
 /* diag[] layout (per object, 4 floats): */
 #define MR_DIAG_LM_ITERATIONS 0       /* LM loop passes executed                                  */
@@ -214,6 +218,24 @@ int mr_pnp_uncert_from_init_grouped(
     const double *const *init_pose, const uint8_t *const *init_mask, const uint8_t *const *init_valid, int B, int P,
     float z_min, int inlier_opt_only, int flags,
     uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream);
+
+/*
+ * mr_pnp_uncert_from_init_grouped for an initialiser that ran with MR_EPNP_DEFER_REFIT (1 <= ncalls <= 4; one call is a launch set of
+ * one): the LM launch loads each object's correspondences ONCE and runs the initialiser's last step — the three pose candidates of the
+ * re-fit on the inliers, pnp_uncert_cpu.py:52-57's cv2.solvePnP inside solvePnPRansac — before the LM.  init_pose (B,4) f64, init_valid
+ * (B) u8 and epnp_diag (B,4) f32 (array or entries NULL: none) are OUTPUTS here, with the values mr_epnp_ransac_* would have written;
+ * init_mask is the initialiser's.  workspace = the one given to mr_epnp_ransac_* (same B, P, ncalls), untouched in between.  One launch,
+ * one pass over the correspondences and one workgroup residency less per call than the two entry points one after the other; results
+ * identical, bit for bit.
+ */
+int mr_pnp_uncert_from_epnp_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *u_range, const float *const *v_range, int range_batch,
+    double *const *init_pose, const uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *epnp_diag, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag,
+    const void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The reference's eigenvalue rule for ill-conditioned Hessians (pnp_uncert.py:77-85), applied per object to the outputs of

@@ -19,6 +19,7 @@ MR_F32, MR_F16, MR_F64, MR_BF16 = 0, 1, 2, 3
 MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
 MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES, MR_ANY_ORDER = 0x4, 0x8, 0x10, 0x20
 MR_EPNP_REFIT_F32 = 0x40
+MR_EPNP_DEFER_REFIT = 0x80
 MR_WAVES_SHIFT = 8
 MR_LM_MAXIT_SHIFT = 16
 MR_EPNP_FIRST_ROUND_SHIFT = 24
@@ -89,6 +90,9 @@ def load():
     lib.mr_pnp_uncert_from_init_grouped.restype = i32
     lib.mr_pnp_uncert_from_init_grouped.argtypes = [i32, vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, f32, i32, i32,
                                                     vp, vp, vp, vp, vp, vp, vp]
+    lib.mr_pnp_uncert_from_epnp_grouped.restype = i32
+    lib.mr_pnp_uncert_from_epnp_grouped.argtypes = [i32, vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, i32,
+                                                    vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.mr_cov_symeig_rule.restype = i32
     lib.mr_cov_symeig_rule.argtypes = [vp, vp, i32, vp, vp]
     lib.mr_pnp_exact_hessian_batched.restype = i32
@@ -140,5 +144,5 @@ def check(code):
 
 
 EXPORTED_SYMBOLS = ('mr_pnp_version', 'mr_spin', 'mr_pick_waves', 'mr_pnp_error_string', 'mr_pnp_last_hip_error', 'mr_pnp_device_count',
-                    'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_ransac_grouped', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_pnp_uncert_from_init_grouped', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
+                    'mr_pnp_uncert_batched', 'mr_epnp_ransac_batched', 'mr_epnp_ransac_grouped', 'mr_epnp_workspace_bytes', 'mr_pnp_uncert_from_init_batched', 'mr_pnp_uncert_from_init_grouped', 'mr_pnp_uncert_from_epnp_grouped', 'mr_cov_symeig_rule', 'mr_pnp6_refine_batched', 'mr_pnp_exact_hessian_batched', 'pnp_uncert', 'mr_noc_decode_batched', 'mr_pnp_from_head_batched', 'mr_nms_bev_batched', 'pnp_noc_uncert', 'pnp_noc_cov_uncert', 'mr_pnp_noc_batched',
                     'mr_kitti_overlaps', 'mr_kitti_match_workspace_bytes', 'mr_kitti_match', 'mr_roi_align_avg')

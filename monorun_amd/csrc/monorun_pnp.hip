@@ -877,10 +877,20 @@ int launch(const PnpArgs &a, hipStream_t st) {
     return MR_OK;
 }
 
+int grant_lds(const void *fn, size_t lds);
+
 template <typename T, int WPO>
-int launch_ext(const PnpArgs &a, hipStream_t st, const PnpCallTable *tbl = nullptr) {
+int launch_ext(const PnpArgs &a, hipStream_t st, const PnpCallTable *tbl = nullptr, const EpnpRefitIn *rf = nullptr) {
     const size_t lds = lds_bytes(a, WPO);
     if (lds > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
+    if (rf) {                               // the initialiser's re-fit as this launch's prologue (mr_pnp_uncert_from_epnp_grouped)
+        if (!tbl) return MR_ERR_BAD_ARGUMENT;
+        int r;
+        if (lds > 48 * 1024 && (r = grant_lds((const void *)pnp_uncert_refit_kernel<T, WPO>, lds)) != MR_OK) return r;
+        hipLaunchKernelGGL((pnp_uncert_refit_kernel<T, WPO>), dim3(a.B), dim3(64 * WPO), lds, st, a, *tbl, *rf);
+        HIP_TRY(hipGetLastError());
+        return MR_OK;
+    }
     if (tbl) {                              // the objects of several calls: the kernel that takes the call table as a second argument
         if (lds > 48 * 1024) {
             static std::mutex mu; static size_t granted[kMaxDevices] = {};
@@ -916,7 +926,7 @@ int launch_ext(const PnpArgs &a, hipStream_t st, const PnpCallTable *tbl = nullp
 }
 
 template <typename T>
-int launch_wpo(PnpArgs &a, int wpo, hipStream_t st, const PnpCallTable *tbl = nullptr) {
+int launch_wpo(PnpArgs &a, int wpo, hipStream_t st, const PnpCallTable *tbl = nullptr, const EpnpRefitIn *rf = nullptr) {
     a.elem_size = (int)sizeof(T);
     a.vec = (!a.from_head && a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;      // channel-planar rows: coalesced per-point loads
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
@@ -926,9 +936,9 @@ int launch_wpo(PnpArgs &a, int wpo, hipStream_t st, const PnpCallTable *tbl = nu
         if (wpo < 2) wpo = 2;
         if (wpo == 3) wpo = 4;
         switch (wpo) {
-            case 2: return launch_ext<T, 2>(a, st, tbl);
-            case 4: return launch_ext<T, 4>(a, st, tbl);
-            case 8: return launch_ext<T, 8>(a, st, tbl);
+            case 2: return launch_ext<T, 2>(a, st, tbl, rf);
+            case 4: return launch_ext<T, 4>(a, st, tbl, rf);
+            case 8: return launch_ext<T, 8>(a, st, tbl, rf);
             default: return MR_ERR_BAD_ARGUMENT;
         }
     }
@@ -1018,7 +1028,13 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
     a.vec = (a.s2[1] == 1 && a.sw[1] == 1 && a.s3[1] == 1) ? 1 : 0;
     a.nca = (((a.P + 63) / 64) + 3) & ~3;
     a.nla = a.plan.n_leaves > 0 ? a.plan.n_leaves : 1;
-    const size_t lds_f = epnp_front_lds_bytes(a), lds_c = epnp_consensus_lds_bytes(a), lds_r = epnp_refit_lds_bytes(a);
+#ifndef MR_EP_LDS_PAD_CONS
+#define MR_EP_LDS_PAD_CONS 0      // development aid: extra LDS per workgroup of the consensus / re-fit launch (residency experiments)
+#endif
+#ifndef MR_EP_LDS_PAD_REFIT
+#define MR_EP_LDS_PAD_REFIT 0
+#endif
+    const size_t lds_f = epnp_front_lds_bytes(a), lds_c = epnp_consensus_lds_bytes(a) + MR_EP_LDS_PAD_CONS, lds_r = epnp_refit_lds_bytes(a) + MR_EP_LDS_PAD_REFIT;
     if (lds_f > dev_info().lds_per_cu || lds_c > dev_info().lds_per_cu || lds_r > dev_info().lds_per_cu) return MR_ERR_UNSUPPORTED;
     const size_t need = epnp_work_bytes(a.B, a.P, nullptr, nullptr);
     unsigned char *base = (unsigned char *)workspace;
@@ -1073,7 +1089,8 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
         }
         hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);      // (8 / 4 / 2 quads per wave: 67 / 68 / 102 us against 55 us)
-        hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
+        if (!(a.flags & MR_EPNP_DEFER_REFIT))                  // else: the LM launch carries it (mr_pnp_uncert_from_epnp_grouped)
+            hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
         HIP_TRY(hipGetLastError());
         return MR_OK;
     };
@@ -1135,7 +1152,7 @@ static int pnp_uncert_launch(
     const float *ransac_thr, const double *init_pose, const uint8_t *init_mask, const uint8_t *init_valid, int B, int P,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream,
-    int ncalls = 1, const PnpCallTable::CallPtrs *calls = nullptr) {
+    int ncalls = 1, const PnpCallTable::CallPtrs *calls = nullptr, const EpnpRefitIn *rf = nullptr) {
     if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range ||
@@ -1161,17 +1178,17 @@ static int pnp_uncert_launch(
     PnpCallTable tbl;
     memset(&tbl, 0, sizeof tbl);
     tbl.ncalls = 1; tbl.group_B = B;
-    if (ncalls > 1) {                                   // a launch over the objects of several calls (EXT only): mr_pnp_uncert_from_init_grouped
+    if (ncalls > 1 || rf) {                             // a launch over the objects of several calls (EXT only): mr_pnp_uncert_from_init_grouped / _from_epnp_grouped
         tbl.ncalls = ncalls; a.B = B * ncalls;
         for (int c = 0; c < ncalls; ++c) tbl.call[c] = calls[c];
     }
     const int wpo = widen_for_large_tiles(pick_wpo(a.B, P, flags), a, flags, in_dtype);
     hipStream_t st = (hipStream_t)stream;
-    const PnpCallTable *tp = ncalls > 1 ? &tbl : nullptr;
+    const PnpCallTable *tp = (ncalls > 1 || rf) ? &tbl : nullptr;
     switch (in_dtype) {
-        case MR_F32: return launch_wpo<float>(a, wpo, st, tp);
-        case MR_F16: return launch_wpo<__half>(a, wpo, st, tp);
-        case MR_F64: return launch_wpo<double>(a, wpo, st, tp);
+        case MR_F32: return launch_wpo<float>(a, wpo, st, tp, rf);
+        case MR_F16: return launch_wpo<__half>(a, wpo, st, tp, rf);
+        case MR_F64: return launch_wpo<double>(a, wpo, st, tp, rf);
         default: return MR_ERR_UNSUPPORTED;
     }
 }
@@ -1201,13 +1218,14 @@ int mr_pnp_uncert_from_init_batched(
                              valid, pose, cov, tr_radius, inlier_mask, diag, stream);
 }
 
-int mr_pnp_uncert_from_init_grouped(
+static int pnp_from_init_grouped(
     int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
     const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
     const float *const *cam_mats, int cam_batch, const float *const *u_range, const float *const *v_range, int range_batch,
     const double *const *init_pose, const uint8_t *const *init_mask, const uint8_t *const *init_valid, int B, int P,
     float z_min, int inlier_opt_only, int flags,
-    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream) {
+    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream,
+    EpnpRefitIn *rf = nullptr, float *const *epnp_diag = nullptr) {
     if (ncalls < 1 || ncalls > 4 || B < 0) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !init_pose || !init_mask || !init_valid ||
@@ -1230,10 +1248,42 @@ int mr_pnp_uncert_from_init_grouped(
         q.init_pose = init_pose[c] - o * 4; q.init_mask = init_mask[c] - o * P; q.init_valid = init_valid[c] - o;
         q.valid = valid[c] - o; q.pose = pose[c] - o * 4; q.cov = cov[c] ? cov[c] - o * 16 : nullptr; q.tr = tr_radius[c] - o;
         q.mask = with_mask ? inlier_mask[c] - o * P : nullptr; q.diag = with_diag ? diag[c] - o * 4 : nullptr;
+        if (rf) rf->diag[c] = (epnp_diag && epnp_diag[c]) ? epnp_diag[c] - o * 4 : nullptr;
     }
     return pnp_uncert_launch(x2d[0], x2d_strides, istd[0], istd_strides, x3d[0], x3d_strides, in_dtype, cam_mats[0], cam_batch, u_range[0], v_range[0], range_batch,
                              nullptr, init_pose[0], init_mask[0], init_valid[0], B, P, z_min, 0.0f, inlier_opt_only, flags,
-                             valid[0], pose[0], cov[0], tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp);
+                             valid[0], pose[0], cov[0], tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp, rf);
+}
+
+int mr_pnp_uncert_from_init_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *u_range, const float *const *v_range, int range_batch,
+    const double *const *init_pose, const uint8_t *const *init_mask, const uint8_t *const *init_valid, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream) {
+    return pnp_from_init_grouped(ncalls, x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, u_range, v_range, range_batch,
+                                 init_pose, init_mask, init_valid, B, P, z_min, inlier_opt_only, flags, valid, pose, cov, tr_radius, inlier_mask, diag, stream);
+}
+
+int mr_pnp_uncert_from_epnp_grouped(
+    int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
+    const void *const *x3d, const int64_t *x3d_strides, int in_dtype,
+    const float *const *cam_mats, int cam_batch, const float *const *u_range, const float *const *v_range, int range_batch,
+    double *const *init_pose, const uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *epnp_diag, int B, int P,
+    float z_min, int inlier_opt_only, int flags,
+    uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag,
+    const void *workspace, size_t workspace_bytes, void *stream) {
+    if (ncalls < 1 || ncalls > kEpMaxGroup || B < 0 || P < 4) return MR_ERR_BAD_ARGUMENT;
+    if (B == 0) return MR_OK;
+    if (!workspace || workspace_bytes < epnp_work_bytes(B * ncalls, P, nullptr, nullptr)) return MR_ERR_BAD_ARGUMENT;
+    EpnpRefitIn rf;
+    memset(&rf, 0, sizeof rf);
+    epnp_work_bytes(B * ncalls, P, &rf.w, (unsigned char *)const_cast<void *>(workspace));
+    rf.B = (long long)B * ncalls;
+    return pnp_from_init_grouped(ncalls, x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, u_range, v_range, range_batch,
+                                 (const double *const *)init_pose, init_mask, (const uint8_t *const *)init_valid, B, P, z_min, inlier_opt_only, flags,
+                                 valid, pose, cov, tr_radius, inlier_mask, diag, stream, &rf, epnp_diag);
 }
 
 static int epnp_ransac_launch(
@@ -1254,6 +1304,7 @@ static int epnp_ransac_launch(
         if ((ransac_thr && ransac_thr[c] != nullptr) != with_thr || (diag && diag[c] != nullptr) != with_diag) return MR_ERR_BAD_ARGUMENT;     // all or none
     }
     if (debug_hypotheses && ncalls != 1) return MR_ERR_BAD_ARGUMENT;
+    if ((flags & MR_EPNP_DEFER_REFIT) && !workspace) return MR_ERR_BAD_ARGUMENT;       // the LM launch that finishes the job needs the workspace
     const size_t esize = in_dtype == MR_F64 ? 8 : (in_dtype == MR_F32 ? 4 : 2);
     EpnpStageArgs sa;
     memset(&sa, 0, sizeof sa);

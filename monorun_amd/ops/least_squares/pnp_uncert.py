@@ -141,6 +141,53 @@ def pnp_uncert_from_init_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, 
     return valid, pose, cov, tr, mask, diag
 
 
+def pnp_uncert_epnp_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=1.0,
+                           epnp_ransac_thres=None, inlier_opt_only=False, flags=0, max_iters=30, with_diag=False, first_round=None):
+    """The reference's flow in one call: ``epnp_ransac_device`` with MR_EPNP_DEFER_REFIT, then ``mr_pnp_uncert_from_epnp_grouped`` — the LM +
+    covariance launch that also runs the initialiser's last step (the re-fit's pose candidates) on the tile it loads anyway.  Same results,
+    bit for bit, as ``epnp_ransac_device`` followed by ``pnp_uncert_from_init_device``; one launch and one pass over the correspondences
+    less.  Returns (valid, pose, cov, tr, mask, diag|None, init_pose f64 (B,4), init_valid u8 (B,))."""
+    lib = _lib.load()
+    dev = coords_2d.device
+    if dev.type != 'cuda':
+        raise RuntimeError('monorun_amd EPnP/RANSAC runs on an MI355X only (no CPU fallback)')
+    iflags = int(flags) & 0x47                     # the bits the initialiser reads: istd mean order, MR_NO_ISTD_MASK, MR_EPNP_REFIT_F32
+    if first_round is not None:
+        iflags |= max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT
+    B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
+    dt = coords_2d.dtype if coords_2d.dtype in _DTYPES else torch.float32
+    prep = lambda t: t.detach() if (t.dtype == dt and t.device == dev) else t.detach().to(device=dev, dtype=dt)
+    x2d, istd, x3d = prep(coords_2d), prep(coords_2d_istd), prep(coords_3d)
+    f32 = dict(device=dev, dtype=torch.float32)
+    cam = cam_mats.detach().to(**f32).reshape(-1, 3, 3).contiguous()
+    ur = u_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    vr = v_range.detach().to(**f32).reshape(-1, 2).contiguous()
+    thr = epnp_ransac_thres.detach().to(**f32).reshape(-1).contiguous() if epnp_ransac_thres is not None else None
+    init_pose = torch.empty(B, 4, device=dev, dtype=torch.float64)
+    init_mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    init_valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    valid = torch.empty(B, device=dev, dtype=torch.uint8)
+    pose = torch.empty(B, 4, **f32)
+    cov = torch.empty(B, 4, 4, **f32)
+    tr = torch.empty(B, **f32)
+    mask = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    diag = torch.empty(B, 4, **f32) if with_diag else None
+    if B > 0:
+        one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr() if t is not None else None)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            work = torch.empty(int(lib.mr_epnp_workspace_bytes(B, P)), device=dev, dtype=torch.uint8)     # (stream order keeps its reuse safe)
+            head = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[dt], cam.data_ptr(), cam.shape[0]]
+            _lib.check(lib.mr_epnp_ransac_batched(*head, thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres),
+                                                  iflags | _lib.MR_EPNP_DEFER_REFIT, int(max_iters), init_pose.data_ptr(), init_mask.data_ptr(),
+                                                  init_valid.data_ptr(), None, None, work.data_ptr(), work.numel(), st))
+            _lib.check(lib.mr_pnp_uncert_from_epnp_grouped(
+                1, one(x2d), _strides(x2d), one(istd), _strides(istd), one(x3d), _strides(x3d), _DTYPES[dt], one(cam), cam.shape[0], one(ur), one(vr), ur.shape[0],
+                one(init_pose), one(init_mask), one(init_valid), None, B, P, float(z_min), int(bool(inlier_opt_only)), int(flags),
+                one(valid), one(pose), one(cov), one(tr), one(mask), one(diag), work.data_ptr(), work.numel(), st))
+    return valid, pose, cov, tr, mask, diag, init_pose, init_valid
+
+
 def cov_symeig_rule_device(valid_u8, cov, with_eigs=False):
     """The reference's eigenvalue rule (pnp_uncert.py:77-85) applied IN PLACE to (valid u8 (B,), cov f32 (B,4,4)):
     objects with lambda_min(h) <= max(1e-6 lambda_max(h), 0) become invalid and get cov = I (``mr_cov_symeig_rule``)."""
@@ -218,8 +265,12 @@ class PnPEpnpLaunch:
 
     def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=0.6,
                  epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False, first_round=None,
-                 out=None, mask=None, work=None):
-        """out: an object with valid / pose / cov / tr tensors to write the results into (e.g. the typed views of
+                 out=None, mask=None, work=None, fused=True):
+        """fused (default): the initialiser stops before its last launch (MR_EPNP_DEFER_REFIT) and the LM launch runs the re-fit's pose
+        candidates as its prologue (``mr_pnp_uncert_from_epnp_grouped``: one launch and one pass over the correspondences less; same
+        results, bit for bit); False: the two entry points one after the other (``mr_epnp_ransac_batched``, then
+        ``mr_pnp_uncert_from_init_batched``).
+        out: an object with valid / pose / cov / tr tensors to write the results into (e.g. the typed views of
         parallel.PackedResults: the kernel then writes straight into the buffer a collective sends); mask: the (B,P) uint8 inlier-mask
         buffer; work: a uint8 workspace of at least mr_epnp_workspace_bytes(B, P) bytes that SEVERAL launches may share when they
         only ever run on one stream (stream order keeps that safe).  All three default to tensors of the launch's own."""
@@ -261,10 +312,15 @@ class PnPEpnpLaunch:
         self.args_lm = head + [ur.data_ptr(), vr.data_ptr(), ur.shape[0], self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
                                B, P, float(z_min), int(bool(inlier_opt_only)), int(flags), self.valid.data_ptr(), self.pose.data_ptr(), self.cov.data_ptr(),
                                self.tr.data_ptr(), self.mask.data_ptr(), self.diag.data_ptr() if self.diag is not None else None]
+        self.fused = bool(fused)
+        if self.fused:
+            self._single = PnPEpnpGroupLaunch([self], work=self.work, lm='fused')
 
     def run(self, stream=None):
         if self.B == 0:
             return
+        if self.fused:
+            return self._single.run(stream)
         st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
         with torch.cuda.device(self.dev):                 # the library launches on the CURRENT HIP device
             code = self.lib.mr_epnp_ransac_batched(*self.args_init, st)
@@ -282,9 +338,12 @@ class PnPEpnpGroupLaunch:
     initialiser's stages are latency chains that fill a fraction of the chip, so a ``PnPPipeline`` of depth 4 that is fed groups
     of two keeps EIGHT calls' stages in flight (measured on MI355X, reference flow, 1024-object calls: DESIGN.md section 3)."""
 
-    def __init__(self, launches, work=None, lm='grouped'):
-        """lm: how the members' LM + covariance launches are issued behind the set's initialiser — 'grouped' (default): ONE launch over the
-        objects of all members (``mr_pnp_uncert_from_init_grouped``: the set pays its slowest object once); 'side_by_side': one launch per
+    def __init__(self, launches, work=None, lm='fused'):
+        """lm: how the members' LM + covariance launches are issued behind the set's initialiser — 'fused' (default): ONE launch over the
+        objects of all members that also carries the initialiser's last step, the re-fit's pose candidates (MR_EPNP_DEFER_REFIT +
+        ``mr_pnp_uncert_from_epnp_grouped``: one launch and one pass over the correspondences less); 'grouped': ONE launch over the
+        objects of all members behind the complete initialiser (``mr_pnp_uncert_from_init_grouped``: the set pays its slowest object
+        once); 'side_by_side': one launch per
         member, the second and later ones with MR_ANY_ORDER; 'serial': one per member in stream order.  Same results.
         work: a uint8 workspace of at least mr_epnp_workspace_bytes(len(launches) * B, P) bytes (shared between groups that only
         ever run on one stream), or None to allocate one."""
@@ -307,10 +366,11 @@ class PnPEpnpGroupLaunch:
         need = int(self.lib.mr_epnp_workspace_bytes(n * f.B, P)) if f.B > 0 else 0
         self.work = work if work is not None else torch.empty(need, device=f.dev, dtype=torch.uint8)
         assert self.work.dtype == torch.uint8 and self.work.numel() >= need and self.work.data_ptr() % 256 == 0
-        self.args = [n, x2d, ai[1], istd, ai[3], x3d, ai[5], ai[6], cam, ai[8], thr, f.B, P, ai[12], ai[13], ai[14],
+        if lm not in ('fused', 'grouped', 'side_by_side', 'serial'):
+            raise ValueError("lm must be 'fused', 'grouped', 'side_by_side' or 'serial'")
+        self.args = [n, x2d, ai[1], istd, ai[3], x3d, ai[5], ai[6], cam, ai[8], thr, f.B, P, ai[12],
+                     int(ai[13]) | (_lib.MR_EPNP_DEFER_REFIT if lm == 'fused' else 0), ai[14],
                      ipose, imask, ivalid, idiag, self.work.data_ptr(), self.work.numel()]
-        if lm not in ('grouped', 'side_by_side', 'serial'):
-            raise ValueError("lm must be 'grouped', 'side_by_side' or 'serial'")
         al = f.args_lm
         lm_same = lambda m: (m.args_lm[11] == al[11] and m.args_lm[17:20] == al[17:20] and (m.args_lm[25] is None) == (al[25] is None))
         if not all(lm_same(m) for m in self.members):
@@ -321,6 +381,7 @@ class PnPEpnpGroupLaunch:
         la = self._lm_arrays
         self.args_lm = [n, x2d, al[1], istd, al[3], x3d, al[5], al[6], cam, al[8], la[9], la[10], al[11], la[12], la[13], la[14], f.B, P, al[17], al[18], al[19],
                         la[20], la[21], la[22], la[23], la[24], la[25]]
+        self.args_fused = self.args_lm[:16] + [idiag] + self.args_lm[16:] + [self.work.data_ptr(), self.work.numel()]
         self._lm_any = []
         for m in self.members:                             # args_lm with MR_ANY_ORDER in its flags (argument 19 of mr_pnp_uncert_from_init_batched)
             a = list(m.args_lm)
@@ -333,6 +394,12 @@ class PnPEpnpGroupLaunch:
         st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
         with torch.cuda.device(self.dev):
             code = self.lib.mr_epnp_ransac_grouped(*self.args, st)
+            if self.lm == 'fused':
+                if not code:
+                    code = self.lib.mr_pnp_uncert_from_epnp_grouped(*self.args_fused, st)
+                if code:
+                    _lib.check(code)
+                return
             if not code and self.lm == 'grouped' and len(self.members) > 1:
                 code = self.lib.mr_pnp_uncert_from_init_grouped(*self.args_lm, st)
                 if code:
@@ -557,10 +624,9 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
         if initialiser is None:
             initialiser = DEFAULT_INITIALISER
         if initialiser == 'epnp':
-            ini, imask, ivalid, _, _ = epnp_ransac_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, epnp_istd_thres=epnp_istd_thres,
-                                                          epnp_ransac_thres=epnp_ransac_thres, first_round=epnp_first_round)
-            valid, pose, cov, _, mask, _ = pnp_uncert_from_init_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
-                                                                       ini, imask, ivalid, z_min=z_min, inlier_opt_only=inlier_opt_only)
+            valid, pose, cov, _, mask = pnp_uncert_epnp_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=z_min,
+                                                               epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=epnp_ransac_thres,
+                                                               inlier_opt_only=inlier_opt_only, first_round=epnp_first_round)[:5]
         elif initialiser == 'k0':
             valid, pose, cov, _, mask, _ = pnp_uncert_device(
                 coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=z_min,

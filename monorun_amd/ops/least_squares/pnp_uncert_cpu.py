@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from ... import _lib
-from .pnp_uncert import DEFAULT_INITIALISER, epnp_ransac_device, pnp_uncert_device, pnp_uncert_from_init_device
+from .pnp_uncert import DEFAULT_INITIALISER, pnp_uncert_device, pnp_uncert_epnp_device
 
 
 def _to_dev(a, dev):
@@ -59,9 +59,8 @@ def u2d_pnp_cpu(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range
     if initialiser is None:
         initialiser = DEFAULT_INITIALISER
     if initialiser == 'epnp':
-        ini, imask, ivalid, _, _ = epnp_ransac_device(x2d, istd, x3d, cam, epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=thr, first_round=epnp_first_round)
-        valid, pose, cov, tr, mask, _ = pnp_uncert_from_init_device(x2d, istd, x3d, cam, ur, vr, ini, imask, ivalid, z_min=z_min,
-                                                                    inlier_opt_only=inlier_opt_only, flags=flags)
+        valid, pose, cov, tr, mask = pnp_uncert_epnp_device(x2d, istd, x3d, cam, ur, vr, z_min=z_min, epnp_istd_thres=epnp_istd_thres, epnp_ransac_thres=thr,
+                                                            inlier_opt_only=inlier_opt_only, flags=flags, first_round=epnp_first_round)[:5]
     elif initialiser == 'k0':
         valid, pose, cov, tr, mask, _ = pnp_uncert_device(x2d, istd, x3d, cam, ur, vr, z_min=z_min, epnp_istd_thres=epnp_istd_thres,
                                                           epnp_ransac_thres=thr, inlier_opt_only=inlier_opt_only, flags=flags)

@@ -361,14 +361,20 @@ def test_grouped_calls_equal_the_calls_one_by_one(dev):
     for x in batches[4:6]:                                # two batches with a camera per object
         x[3] = (x[3].reshape(1, 3, 3).repeat(192, 1, 1) * torch.linspace(0.97, 1.03, 192, device=dev)[:, None, None]).contiguous()
     kw = dict(z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True)
-    def solo(x, diag=False):
-        l = PnPEpnpLaunch(*x[:6], epnp_ransac_thres=x[6], with_diag=diag, **kw); l.run(); torch.cuda.synchronize(); return l
-    refs = [solo(x, diag=(i < 2)) for i, x in enumerate(batches)]
+    def solo(x, diag=False, fused=False):
+        l = PnPEpnpLaunch(*x[:6], epnp_ransac_thres=x[6], with_diag=diag, fused=fused, **kw); l.run(); torch.cuda.synchronize(); return l
+    refs = [solo(x, diag=(i < 2)) for i, x in enumerate(batches)]          # the two entry points one after the other
     def same(l, r):
         return (torch.equal(l.valid, r.valid) and torch.equal(l.pose, r.pose) and torch.equal(l.cov, r.cov) and torch.equal(l.tr, r.tr) and torch.equal(l.mask, r.mask)
                 and torch.equal(l.init_pose, r.init_pose) and torch.equal(l.init_mask, r.init_mask) and torch.equal(l.init_valid, r.init_valid))
+    # the default of a single launch: the re-fit's pose candidates as the LM launch's prologue (MR_EPNP_DEFER_REFIT + mr_pnp_uncert_from_epnp_grouped)
+    for i, x in enumerate(batches):
+        l = solo(x, diag=(i < 2), fused=True)
+        assert same(l, refs[i]), i
+        if i < 2:
+            assert torch.equal(l.init_diag, refs[i].init_diag) and torch.equal(l.diag, refs[i].diag)
     for members, diag in (([0, 1], True), ([2, 3, 6], False), ([0, 1, 2, 3], False), ([4, 5], False), ([6], False)):
-        for lm in ('grouped', 'side_by_side', 'serial'):            # one LM launch over the set (mr_pnp_uncert_from_init_grouped) / one per member
+        for lm in ('fused', 'grouped', 'side_by_side', 'serial'):   # one LM launch over the set (with / without the re-fit in it) / one per member
             ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], with_diag=diag, **kw) for i in members]
             g = PnPEpnpGroupLaunch(ls, lm=lm)
             g.run(); g.run(); torch.cuda.synchronize()
@@ -401,6 +407,64 @@ def test_grouped_calls_equal_the_calls_one_by_one(dev):
     assert lib.mr_epnp_ransac_grouped(*bad, None) == -1
     bad = list(g.args); bad[21] = 1024
     assert lib.mr_epnp_ransac_grouped(*bad, None) == -1                   # workspace too small for the whole group
+    torch.cuda.synchronize()
+
+
+def test_refit_inside_the_lm_launch_equals_the_two_entry_points(dev):
+    """MR_EPNP_DEFER_REFIT + mr_pnp_uncert_from_epnp_grouped (what pnp_uncert / PnPUncert / u2d_pnp_cpu run by default): the initialiser stops
+    before its last launch and the LM launch computes the re-fit's pose candidates on the tile it loads anyway — every output, the
+    initialiser's hand-over included, equals mr_epnp_ransac_batched followed by mr_pnp_uncert_from_init_batched bit for bit: both layouts,
+    fp32 / fp16 / fp64 storage, 2 / 4 / 8 waves per object (the re-fit's three candidates on 2 waves: one wave takes two), per-object
+    cameras, plain EPnP (no thresholds), failures, five-candidate objects, NaN / degenerate inputs, P = 4; and the argument checks."""
+    import ctypes
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device, pnp_uncert_epnp_device
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    def both(x, flags=0, **kw):
+        ini, im, iv, _, _ = epnp_ransac_device(x[0], x[1], x[2], x[3], epnp_istd_thres=0.6, epnp_ransac_thres=x[6])
+        two = pnp_uncert_from_init_device(*x[:6], ini, im, iv, z_min=0.5, inlier_opt_only=True, flags=flags, with_diag=True)
+        one = pnp_uncert_epnp_device(*x[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=x[6], inlier_opt_only=True, flags=flags, with_diag=True)
+        torch.cuda.synchronize()
+        for k in range(6):
+            assert torch.equal(one[k], two[k]) or (one[k].dtype.is_floating_point and torch.equal(torch.nan_to_num(one[k], nan=-7.0), torch.nan_to_num(two[k], nan=-7.0))), (k, kw)
+        assert torch.equal(one[6], ini) and torch.equal(one[7], iv), kw
+        return one
+    for planar in (True, False):
+        for dtype in (np.float32, np.float16, np.float64):
+            b = syn.make_batch(B=96, hw=(12 if dtype == np.float16 else 28), seed=int(rng.integers(1 << 30)))
+            x = [np.array(a, copy=True) for a in syn.pnp_boundary(b, planar=planar)]
+            P = x[0].shape[1]
+            for i in range(0, 12):                         # gross outliers: many RANSAC iterations
+                bad = rng.random(P) < 0.5
+                x[2][i, bad] += rng.normal(0, 0.8, (int(bad.sum()), 3)).astype(np.float32)
+            x[6][12:16] = 1e-4                             # RANSAC fails
+            for i in range(16, 20):                        # exactly five candidates
+                x[1][i] = 1e-3; x[1][i, rng.choice(P, 5, replace=False)] = 1.0
+            x[2][20] = 0.0; x[0][21, 3] = np.nan; x[2][22, :, 1] = 0.0
+            x[3] = np.repeat(x[3].reshape(1, 3, 3), 96, 0) * np.linspace(0.97, 1.03, 96, dtype=np.float32)[:, None, None]
+            d = [_t(dev, np.ascontiguousarray(a.astype(dtype)) if k < 3 else a) for k, a in enumerate(x)]
+            for w in (0, 2, 4, 8):
+                one = both(d, flags=w << 8, planar=planar, dtype=dtype, w=w)
+            assert int(one[0].sum()) > 60 and not bool(one[7][12:16].any())
+    x = [_t(dev, a) for a in syn.pnp_boundary(syn.make_batch(B=64, seed=5), planar=True)]
+    x[6] = None                                            # plain cv2.solvePnP(EPNP) on the istd candidates
+    both(x, mode='plain')
+    x4 = [_t(dev, np.ascontiguousarray(a[:, :4]) if a.ndim == 3 and k < 3 else a) for k, a in enumerate(syn.pnp_boundary(syn.make_batch(B=8, seed=6), planar=False))]
+    both(x4, mode='P=4')
+    # argument checks: deferring needs the caller's workspace; the LM side needs it too, large enough, and 1..4 calls
+    x = [_t(dev, a) for a in syn.pnp_boundary(syn.make_batch(B=32, seed=7), planar=True)]
+    st = lambda t: (ctypes.c_int64 * 3)(*t.stride())
+    ip, im, iv = torch.empty(32, 4, device=dev, dtype=torch.float64), torch.empty(32, x[0].shape[1], device=dev, dtype=torch.uint8), torch.empty(32, device=dev, dtype=torch.uint8)
+    head = [x[0].data_ptr(), st(x[0]), x[1].data_ptr(), st(x[1]), x[2].data_ptr(), st(x[2]), 0, x[3].data_ptr(), 1]
+    assert lib.mr_epnp_ransac_batched(*head, x[6].data_ptr(), 32, x[0].shape[1], 0.6, _lib.MR_EPNP_DEFER_REFIT, 30, ip.data_ptr(), im.data_ptr(), iv.data_ptr(), None, None, None, 0, None) == -1
+    one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr() if t is not None else None)
+    work = torch.empty(int(lib.mr_epnp_workspace_bytes(32, x[0].shape[1])), device=dev, dtype=torch.uint8)
+    outs = [torch.empty(32, device=dev, dtype=torch.uint8), torch.empty(32, 4, device=dev), torch.empty(32, 16, device=dev), torch.empty(32, device=dev), torch.empty(32, x[0].shape[1], device=dev, dtype=torch.uint8)]
+    def lm(ncalls=1, wptr=work.data_ptr(), wbytes=work.numel()):
+        return lib.mr_pnp_uncert_from_epnp_grouped(ncalls, one(x[0]), st(x[0]), one(x[1]), st(x[1]), one(x[2]), st(x[2]), 0, one(x[3]), 1, one(x[4]), one(x[5]), 1,
+                                                   one(ip), one(im), one(iv), None, 32, x[0].shape[1], 0.5, 1, 0, *[one(o) for o in outs], one(None), wptr, wbytes, None)
+    assert lm(ncalls=0) == -1 and lm(ncalls=5) == -1 and lm(wptr=None) == -1 and lm(wbytes=work.numel() - 1) == -1
     torch.cuda.synchronize()
 
 

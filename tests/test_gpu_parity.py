@@ -620,7 +620,7 @@ def test_bench_line_describes_the_regime_it_measured():
     chip = d['value'] * rf['algorithmic_bytes_per_launch'] / 1024 / 1e9                   # algorithmic bytes of all calls / wall time
     assert abs(rf['achieved'] - chip) <= 1e-6 * chip and abs(rf['frac'] - chip / 8000.0) <= 1e-9
     dk = rf['dominant_kernel']
-    assert dk['kernel'].startswith('pnp_uncert_kernel<float, ') and dk['kernel'].endswith('true>') and dk['avg_launch_ms'] > 0
+    assert dk['kernel'].startswith('pnp_uncert_refit_kernel<float, ') and dk['avg_launch_ms'] > 0
     assert abs(dk['frac'] - rf['algorithmic_bytes_per_launch'] / (dk['avg_launch_ms'] * 1e-3) / 1e9 / 8000.0) <= 1e-9
     iso = rf['isolated_launch']
     assert iso['kernel_ms_avg'] > dk['avg_launch_ms'] and abs(iso['frac'] - rf['algorithmic_bytes_per_launch'] / (iso['kernel_ms_avg'] * 1e-3) / 1e9 / 8000.0) <= 1e-9

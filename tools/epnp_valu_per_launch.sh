@@ -11,7 +11,7 @@ by = collections.OrderedDict()
 for r in rows:
     k = int(r['Dispatch_Id'])
     by.setdefault(k, {'name': r['Kernel_Name']})[r['Counter_Name']] = float(r['Counter_Value'])
-d = [v for k, v in sorted(by.items()) if 'epnp_' in v['name'] or 'pnp_uncert_kernel' in v['name']]
+d = [v for k, v in sorted(by.items()) if 'epnp_' in v['name'] or 'pnp_uncert_' in v['name']]
 # group into calls by front kernel
 calls, cur = [], None
 for v in d:

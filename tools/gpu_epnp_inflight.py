@@ -18,7 +18,7 @@ for depth in [int(v) for v in os.environ.get('DEPTHS', '1,4').split(',')]:
     calls = le
     if G > 1:
         le = [PnPEpnpGroupLaunch(calls[k:k + G]) for k in range(0, len(calls) - G + 1, G)]
-    res = []
+    res = []; host = []
     for rep in range(5):
         for i in range(8):
             pipe.submit(le[i % len(le)], slot=i % len(le))
@@ -26,7 +26,8 @@ for depth in [int(v) for v in os.environ.get('DEPTHS', '1,4').split(',')]:
         t0 = time.perf_counter()
         for i in range(96):
             pipe.submit(le[i % len(le)], slot=i % len(le))
+        host.append((time.perf_counter() - t0) / 96 * 1e6)
         pipe.drain()
         res.append(BO * G * 96 / (time.perf_counter() - t0) / 1e6)
-    print(f'{tag}: depth {depth} (streams found {pipe.depth}, {pipe.overlap_test}): ' + ' '.join(f'{r:5.2f}' for r in res) + f'  median {np.median(res):.2f} M solves/s; pose checksum {sum(float(l.pose.double().sum()) for l in calls):.9f}', flush=True)
+    print(f'{tag}: depth {depth} (streams found {pipe.depth}, {pipe.overlap_test}): ' + ' '.join(f'{r:5.2f}' for r in res) + f'  median {np.median(res):.2f} M solves/s; host {np.median(host):.0f} us per submit of {np.median([BO * G / r for r in res]):.0f}; pose checksum {sum(float(l.pose.double().sum()) for l in calls):.9f}', flush=True)
     del pipe, le

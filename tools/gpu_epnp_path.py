@@ -1,16 +1,15 @@
-"""The EPnP/RANSAC initialiser launch + the LM launch behind it, REPS times on config-2 batch 0, for the profiler (development aid)."""
+"""The reference flow as the boundary runs it (the initialiser's six launches + the LM launch that carries its re-fit), REPS times on config-2 batch 0, for the profiler (development aid)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn
-from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_epnp_device
 dev = torch.device('cuda:0')
 REPS = int(os.environ.get('REPS', 10))
 def dv(a):
     t = torch.from_numpy(np.asarray(a)); d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev); d.copy_(t); return d
 x2d, istd, x3d, K, ur, vr, thr = [dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=1234), planar=True)]
 for _ in range(REPS):
-    ini, im, iv, _, _ = epnp_ransac_device(x2d, istd, x3d, K, epnp_istd_thres=0.6, epnp_ransac_thres=thr)
-    pnp_uncert_from_init_device(x2d, istd, x3d, K, ur, vr, ini, im, iv, z_min=0.5, inlier_opt_only=True)
+    pnp_uncert_epnp_device(x2d, istd, x3d, K, ur, vr, z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=thr, inlier_opt_only=True)
 torch.cuda.synchronize()
 print('ok', REPS)

@@ -5,12 +5,12 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 D=${1:-4}; F=${2:-8}
 rm -rf $R/gpurun_out/ep_trace_if
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ep_trace_if -o t -- env DEPTHS=$D MR_EPNP_FIRST_ROUND=$F python $R/tools/gpu_epnp_inflight.py > $R/gpurun_out/ep_trace_if.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ep_trace_if -o t -- env DEPTHS=$D GROUP=${GROUP:-1} python $R/tools/gpu_epnp_inflight.py > $R/gpurun_out/ep_trace_if.log 2>&1
 python - <<'P'
 import csv, glob, os, collections
 f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/ep_trace_if/**/t_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-rows = [r for r in rows if 'epnp_' in r['Kernel_Name'] or 'pnp_uncert_kernel' in r['Kernel_Name']]
+rows = [r for r in rows if 'epnp_' in r['Kernel_Name'] or 'pnp_uncert_' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 rows = rows[len(rows) // 4:]                      # skip warm-up
 by = collections.defaultdict(list)

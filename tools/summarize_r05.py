@@ -23,7 +23,7 @@ if f:
         n = r['Kernel_Name']
         if 'epnp_front_kernel' in n:
             cur = []; seqs.append(cur)
-        if cur is not None and ('epnp_' in n or 'pnp_uncert_kernel' in n):
+        if cur is not None and ('epnp_' in n or 'pnp_uncert_' in n):
             cur.append((short(n), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp']), int(r['End_Timestamp'])))
     seqs = [q for q in seqs if len(q) == len(seqs[-1])][2:]
     lines.append('the launches of one call of the reference flow on 1024 config-2 objects (batch 0), rocprofv3 kernel trace, averaged over the calls of the trace')
@@ -39,7 +39,7 @@ def per_kernel(sub):
     if f:
         for r in csv.DictReader(open(f)):
             by.setdefault(int(r['Dispatch_Id']), {'name': short(r['Kernel_Name'])})[r['Counter_Name']] = float(r['Counter_Value'])
-    d = [v for k, v in sorted(by.items()) if 'epnp_' in v['name'] or 'pnp_uncert_kernel' in v['name']]
+    d = [v for k, v in sorted(by.items()) if 'epnp_' in v['name'] or 'pnp_uncert_' in v['name']]
     calls, cur = [], None
     for v in d:
         if 'epnp_front' in v['name']:
