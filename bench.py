@@ -67,9 +67,9 @@ def parse():
                     help="reference (default): what the drop-in boundary runs — the reference's flow, cv2.solvePnPRansac(EPNP, 30) restated on the GPU + LM "
                          "+ covariance (PnPUncert built from the reference's config dict); k0: the explicit one-launch fast mode (PnPUncert(initialiser='k0')), "
                          'what rounds 1-4 reported as `value`.  With --flow reference the line carries the fast mode under `k0_fast_mode`')
-    ap.add_argument('--group', type=int, default=int(os.environ.get('MR_BENCH_GROUP', '3')),
+    ap.add_argument('--group', type=int, default=int(os.environ.get('MR_BENCH_GROUP', '5')),
                     help='reference flow, launches in flight: calls whose initialiser launches are issued as ONE launch set (monorun_amd.PnPEpnpGroupLaunch, '
-                         '1..4; every call keeps its own inputs, outputs and LM launch)')
+                         '1..8; every call keeps its own inputs and outputs)')
     ap.add_argument('--workload', choices=['config2', 'stress'], default='config2',
                     help="config2 (default, the metric's configuration) or stress = BASELINE config 5's per-GPU shard: 8192 objects x "
                          '56x56 correspondences, fp16 storage (a parity-test shape; an extra line, never the judged one)')
@@ -278,7 +278,8 @@ def run(args):
     G_SEC = 8
     RING = max(2, int(os.environ.get('MR_BENCH_RING', '4')))
     S = RING * G_SEC                                   # 32 slots: multiple of every L <= 8 and of G_SEC
-    while S % L:
+    LG = max(1, min(8, args.group)) if (ref_flow and L > 1 and not stress and not oversub) else 1      # calls per launch set (reference flow)
+    while S % L or S % LG:
         S += G_SEC
     row = B_PER_GPU * ROW_BYTES
     gbuf = [torch.zeros(G_SEC * row, dtype=torch.uint8, device=dev) for _ in range(S // G_SEC)]
@@ -292,7 +293,6 @@ def run(args):
     # reference flow: the initialiser's launches hand their intermediate results over in a workspace — one per result slot (a slot is
     # pinned to one pipeline stream, so its launches are stream-ordered), shared by every batch's launch object of that slot; a launch
     # GROUP (calls of consecutive slots issued as one launch set) uses the group's first slot's, sized for the whole group
-    LG = max(1, min(4, args.group)) if (ref_flow and L > 1 and not stress and not oversub) else 1
     works = None
     if ref_flow:
         from monorun_amd import _lib as _mrlib
@@ -674,12 +674,12 @@ def run(args):
                        'flow': ("reference: the drop-in boundary's default — PnPUncert built from the reference's config dict (configs/kitti_car.py:118-126)" if ref_flow else
                                 "k0: the explicit fast mode, PnPUncert(initialiser='k0')"),
                        'stages': ('istd mask + cv2.solvePnPRansac(EPNP, 30 iterations) restated (front / hypotheses / consensus / re-fit launches) + LM (Ceres-1.14 semantics, fp64) '
-                                  '+ covariance: 8 launches per call' if ref_flow else
+                                  '+ covariance: 7 launches per call or launch set (the last one = the re-fit\'s pose candidates, then LM + covariance)' if ref_flow else
                                   'istd mask + K0 consensus initialiser (32 hyp.) + LM (Ceres-1.14 semantics, fp64) + covariance: one fused launch'),
                        'calls_per_launch_set': LG,
                        'launches_in_flight': L, 'launches_in_flight_asked': L_ASKED, 'stream_overlap_test': pipe_of(L_ASKED).overlap_test, 'waves_per_object': {'in_flight': (fl_main >> 8) & 15 or 'library heuristic (4)', 'isolated_launch': (fl_one >> 8) & 15 or 'library heuristic (4)'},
                        'issue': ((f'steps issued on {L} HIP streams by monorun_amd.PnPPipeline, {LG} consecutive steps per launch set (monorun_amd.PnPEpnpGroupLaunch: the '
-                                  "initialiser's launches carry the objects of the set's calls, every call keeps its own input tensors, result buffers and LM launch); "
+                                  "every launch of the set — the initialiser's six and the re-fit / LM / covariance launch — carries the objects of the set's calls, every call keeps its own input tensors and result buffers); "
                                   if LG > 1 else f'steps issued round-robin on {L} HIP streams by monorun_amd.PnPPipeline (one completion event per result buffer); ') +
                                  f'every step is one full {B_PER_GPU}-object call into its own buffers, all outputs complete inside the timed window '
                                  'and verified bit-identical to isolated calls after it') if L > 1 else 'one stream: every launch waits for the previous one',
@@ -688,7 +688,7 @@ def run(args):
             'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          # filled in below: `achieved` / `frac` describe the TIMED REGIME (the kernel instantiation and issue pattern `value` was measured on)
                          'achieved': None, 'frac': None,
-                         'kernel': (f'reference flow, 8 launches per call (epnp_front / epnp_hyp / epnp_consensus x 2 rounds, epnp_refit_betas, epnp_refit, pnp_uncert_kernel<{"__half" if stress else "float"}, {((fl_main >> 8) & 15) or 4}, true>); longest: the LM launch' if ref_flow else
+                         'kernel': (f'reference flow, 7 launches per call or launch set (epnp_front / epnp_hyp / epnp_consensus x 2 rounds, epnp_refit_betas, pnp_uncert_refit_kernel<{"__half" if stress else "float"}, {((fl_main >> 8) & 15) or 4}>); longest: the last one (re-fit prologue + LM + covariance)' if ref_flow else
                                     (f'pnp_uncert_kernel<float, {((fl_main >> 8) & 15) or 4}, false>' if not stress else f'pnp_uncert_kernel<__half, {((fl_main >> 8) & 15) or "auto"}, false>')),
                          'launches_in_flight': L,
                          'traffic': traffic, 'traffic_source': traffic_src,

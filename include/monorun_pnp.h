@@ -174,7 +174,7 @@ int mr_epnp_ransac_batched(
 size_t mr_epnp_workspace_bytes(int B, int P);
 
 /*
- * The same initialiser for SEVERAL calls in one launch set (1 <= ncalls <= 4): call c has its own correspondence tensors x2d[c] /
+ * The same initialiser for SEVERAL calls in one launch set (1 <= ncalls <= 8): call c has its own correspondence tensors x2d[c] /
  * istd[c] / x3d[c], camera cam_mats[c], thresholds ransac_thr[c] and outputs init_pose[c] / init_mask[c] / init_valid[c] / diag[c]
  * (arrays of ncalls device pointers, read on the host); B objects per call, and P, the element strides, in_dtype, cam_batch, istd_thres,
  * flags and max_iters are common (ransac_thr and diag: all NULL or none).  Results are those of ncalls calls of mr_epnp_ransac_batched,
@@ -206,7 +206,7 @@ int mr_pnp_uncert_from_init_batched(
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream);
 
 /*
- * The same launch over the objects of SEVERAL calls (1 <= ncalls <= 4; the companion of mr_epnp_ransac_grouped): arrays of ncalls device
+ * The same launch over the objects of SEVERAL calls (1 <= ncalls <= 8; the companion of mr_epnp_ransac_grouped): arrays of ncalls device
  * pointers (read on the host) for everything a caller owns; B objects per call; P, strides, in_dtype, cam_batch, range_batch, z_min and
  * the flags are common (inlier_mask and diag: all NULL or none).  Results are those of ncalls calls of mr_pnp_uncert_from_init_batched,
  * bit for bit.  One launch lasts as long as its slowest object: carried by one launch, the calls of a launch set pay that tail once.
@@ -220,7 +220,7 @@ int mr_pnp_uncert_from_init_grouped(
     uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream);
 
 /*
- * mr_pnp_uncert_from_init_grouped for an initialiser that ran with MR_EPNP_DEFER_REFIT (1 <= ncalls <= 4; one call is a launch set of
+ * mr_pnp_uncert_from_init_grouped for an initialiser that ran with MR_EPNP_DEFER_REFIT (1 <= ncalls <= 8; one call is a launch set of
  * one): the LM launch loads each object's correspondences ONCE and runs the initialiser's last step — the three pose candidates of the
  * re-fit on the inliers, pnp_uncert_cpu.py:52-57's cv2.solvePnP inside solvePnPRansac — before the LM.  init_pose (B,4) f64, init_valid
  * (B) u8 and epnp_diag (B,4) f32 (array or entries NULL: none) are OUTPUTS here, with the values mr_epnp_ransac_* would have written;

@@ -587,7 +587,7 @@ struct PnpCallTable {
         const void *x2d, *istd, *x3d, *K, *ur, *vr;
         const double *init_pose; const uint8_t *init_mask, *init_valid;
         uint8_t *valid; float *pose, *cov, *tr; uint8_t *mask; float *diag;
-    } call[4];
+    } call[8];          // = kEpMaxGroup
 };
 
 #include "pnp_kernel.inc"
@@ -1226,14 +1226,14 @@ static int pnp_from_init_grouped(
     float z_min, int inlier_opt_only, int flags,
     uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream,
     EpnpRefitIn *rf = nullptr, float *const *epnp_diag = nullptr) {
-    if (ncalls < 1 || ncalls > 4 || B < 0) return MR_ERR_BAD_ARGUMENT;
+    if (ncalls < 1 || ncalls > 8 || B < 0) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !init_pose || !init_mask || !init_valid ||
         !valid || !pose || !tr_radius || !cov) return MR_ERR_BAD_ARGUMENT;
     const bool with_mask = inlier_mask && inlier_mask[0], with_diag = diag && diag[0];
     const size_t esize = in_dtype == MR_F64 ? 8 : (in_dtype == MR_F32 ? 4 : 2);
     const long long ks = (cam_batch == 1) ? 0 : 9, rs = (range_batch == 1) ? 0 : 2;
-    PnpCallTable::CallPtrs cp[4];
+    PnpCallTable::CallPtrs cp[8];
     for (int c = 0; c < ncalls; ++c) {
         if (!x2d[c] || !istd[c] || !x3d[c] || !cam_mats[c] || !u_range[c] || !v_range[c] || !init_pose[c] || !init_mask[c] || !init_valid[c] ||
             !valid[c] || !pose[c] || !tr_radius[c] || (!cov[c] && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;

@@ -331,7 +331,7 @@ class PnPEpnpLaunch:
 
 
 class PnPEpnpGroupLaunch:
-    """Up to four prepared ``PnPEpnpLaunch`` objects of the same shape whose initialisers run as ONE launch set
+    """Up to eight prepared ``PnPEpnpLaunch`` objects of the same shape whose initialisers run as ONE launch set
     (``mr_epnp_ransac_grouped``: every launch of csrc/epnp_stages.inc carries the objects of all members), followed by each
     member's own LM + covariance launch, all on the stream ``run`` is given.  Members keep their inputs and outputs; results are
     bit-identical to running them one by one.  Why: HIP runs the launches of at most four streams side by side and the
@@ -349,8 +349,8 @@ class PnPEpnpGroupLaunch:
         ever run on one stream), or None to allocate one."""
         self.members = list(launches)
         n = len(self.members)
-        if not 1 <= n <= 4:
-            raise ValueError('PnPEpnpGroupLaunch takes 1 to 4 launches')
+        if not 1 <= n <= 8:
+            raise ValueError('PnPEpnpGroupLaunch takes 1 to 8 launches')
         f = self.members[0]
         self.lib, self.dev, self.B = f.lib, f.dev, f.B
         ai = f.args_init

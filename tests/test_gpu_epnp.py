@@ -350,9 +350,9 @@ def test_prepared_reference_flow_launches_in_flight(dev):
 
 
 def test_grouped_calls_equal_the_calls_one_by_one(dev):
-    """mr_epnp_ransac_grouped / PnPEpnpGroupLaunch: the initialiser's launches carry the objects of up to four calls (separate input and
+    """mr_epnp_ransac_grouped / PnPEpnpGroupLaunch: every launch of the set carries the objects of up to eight calls (separate input and
     output tensors, shared workspace), each call's LM launch follows — bit-identical to the calls one by one: per-object cameras and a
-    shared one, with and without the diag output, groups of 2, 3 and 4, a group in flight next to others, and the argument checks."""
+    shared one, with and without the diag output, groups of 1 to 8, a group in flight next to others, and the argument checks."""
     import ctypes
     from monorun_amd import PnPEpnpLaunch, PnPEpnpGroupLaunch, PnPPipeline, _lib
     lib = _lib.load()
@@ -373,7 +373,7 @@ def test_grouped_calls_equal_the_calls_one_by_one(dev):
         assert same(l, refs[i]), i
         if i < 2:
             assert torch.equal(l.init_diag, refs[i].init_diag) and torch.equal(l.diag, refs[i].diag)
-    for members, diag in (([0, 1], True), ([2, 3, 6], False), ([0, 1, 2, 3], False), ([4, 5], False), ([6], False)):
+    for members, diag in (([0, 1], True), ([2, 3, 6], False), ([0, 1, 2, 3], False), ([4, 5], False), ([6], False), ([0, 1, 2, 3, 6], False), ([6, 3, 2, 1, 0, 6, 3, 2], False)):
         for lm in ('fused', 'grouped', 'side_by_side', 'serial'):   # one LM launch over the set (with / without the re-fit in it) / one per member
             ls = [PnPEpnpLaunch(*batches[i][:6], epnp_ransac_thres=batches[i][6], with_diag=diag, **kw) for i in members]
             g = PnPEpnpGroupLaunch(ls, lm=lm)
@@ -393,15 +393,15 @@ def test_grouped_calls_equal_the_calls_one_by_one(dev):
     pipe.drain()
     for l, i in zip(ls, (0, 1, 2, 3, 6, 0)):
         assert same(l, refs[i])
-    # members must agree in shape / camera batching; more than four calls and mixed thresholds are refused by the library
+    # members must agree in shape / camera batching; more than eight calls and mixed thresholds are refused by the library
     with pytest.raises(ValueError):
         PnPEpnpGroupLaunch([refs[0], refs[4]])
     with pytest.raises(ValueError):
         PnPEpnpGroupLaunch([refs[0], solo(mk(77, B=64))])
     with pytest.raises(ValueError):
-        PnPEpnpGroupLaunch(refs[:5])
+        PnPEpnpGroupLaunch([refs[0], refs[1], refs[2], refs[3], refs[6]] * 2)
     g = PnPEpnpGroupLaunch([refs[2], refs[3]])
-    bad = list(g.args); bad[0] = 5
+    bad = list(g.args); bad[0] = 9
     assert lib.mr_epnp_ransac_grouped(*bad, None) == -1
     bad = list(g.args); thr = (ctypes.c_void_p * 2)(g.args[10][0], None); bad[10] = thr
     assert lib.mr_epnp_ransac_grouped(*bad, None) == -1
@@ -464,7 +464,7 @@ def test_refit_inside_the_lm_launch_equals_the_two_entry_points(dev):
     def lm(ncalls=1, wptr=work.data_ptr(), wbytes=work.numel()):
         return lib.mr_pnp_uncert_from_epnp_grouped(ncalls, one(x[0]), st(x[0]), one(x[1]), st(x[1]), one(x[2]), st(x[2]), 0, one(x[3]), 1, one(x[4]), one(x[5]), 1,
                                                    one(ip), one(im), one(iv), None, 32, x[0].shape[1], 0.5, 1, 0, *[one(o) for o in outs], one(None), wptr, wbytes, None)
-    assert lm(ncalls=0) == -1 and lm(ncalls=5) == -1 and lm(wptr=None) == -1 and lm(wbytes=work.numel() - 1) == -1
+    assert lm(ncalls=0) == -1 and lm(ncalls=9) == -1 and lm(wptr=None) == -1 and lm(wbytes=work.numel() - 1) == -1
     torch.cuda.synchronize()
 
 

@@ -1,11 +1,11 @@
-"""One launch set of three calls (PnPEpnpGroupLaunch, the regime `value` is measured in: first round 3, two waves per object in the LM launch), REPS
-times over config-2 batches 0..2, for the profiler (development aid)."""
+"""One launch set of GROUP (default 5) calls (PnPEpnpGroupLaunch, the regime `value` is measured in: first round 3, two waves per object in the LM launch), REPS
+times over config-2 batches 0..GROUP-1, for the profiler (development aid)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn, PnPEpnpLaunch, PnPEpnpGroupLaunch
 dev = torch.device('cuda:0')
-REPS = int(os.environ.get('REPS', 6)); G = int(os.environ.get('GROUP', 3))
+REPS = int(os.environ.get('REPS', 6)); G = int(os.environ.get('GROUP', 5))
 def dv(a):
     t = torch.from_numpy(np.asarray(a)); d = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=dev); d.copy_(t); return d
 bs = [[dv(a) for a in syn.pnp_boundary(syn.make_batch(B=1024, seed=1234 + 7919 * i), planar=True)] for i in range(G)]

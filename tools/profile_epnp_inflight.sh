@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 D=${1:-4}; F=${2:-8}
 rm -rf $R/gpurun_out/ep_trace_if
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ep_trace_if -o t -- env DEPTHS=$D GROUP=${GROUP:-1} python $R/tools/gpu_epnp_inflight.py > $R/gpurun_out/ep_trace_if.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ep_trace_if -o t -- env DEPTHS=$D GROUP=${GROUP:-5} NBATCH=${NBATCH:-20} python $R/tools/gpu_epnp_inflight.py > $R/gpurun_out/ep_trace_if.log 2>&1
 python - <<'P'
 import csv, glob, os, collections
 f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/ep_trace_if/**/t_kernel_trace.csv', recursive=True)[0]
