@@ -1071,7 +1071,12 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
     auto run = [&]() -> int {
         int r;
         if ((r = grant_lds((const void *)epnp_front_kernel<T>, lds_f)) != MR_OK) return r;
-        if ((r = grant_lds((const void *)epnp_consensus_kernel<T>, lds_c)) != MR_OK) return r;
+        // waves per object of the consensus launch: 4; the environment variable MR_EP_CONS_WPO=2 selects the two-wave instantiation (same bits; measured
+        // slower one call at a time AND in launch sets — 11.39 -> 11.21 M solves/s with sets of five, 11.93 -> 11.51 with sets of eight: the launch's
+        // time is throughput work, not waves waiting — profiles/r05_epnp_grouping.txt)
+        static const int cons_env = [] { const char *e = getenv("MR_EP_CONS_WPO"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 0; }();
+        const int cons_wpo = cons_env ? cons_env : 4;
+        if ((r = grant_lds(cons_wpo == 2 ? (const void *)epnp_consensus_kernel<T, 2> : (const void *)epnp_consensus_kernel<T, 4>, lds_c)) != MR_OK) return r;
         if ((r = grant_lds((const void *)epnp_refit_kernel<T>, lds_r)) != MR_OK) return r;
         hipLaunchKernelGGL((epnp_front_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_f, st, ea);
         // The 30 hypotheses of an object are solved in two rounds: [0, first) for every object, the rest only for the objects whose
@@ -1086,7 +1091,8 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             // 16 quads per single-wave workgroup: 8 / 4 per wave (more waves, fewer matrices in lockstep) measured 74 / 140 us against 74 us one call
             // at a time and 5.4 / 4.1 against 6.3 M solves/s in flight (profiles/r04_epnp_quads_per_wave.txt)
             hipLaunchKernelGGL(epnp_hyp_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(64), 0, st, ea);
-            hipLaunchKernelGGL((epnp_consensus_kernel<T>), dim3(a.B), dim3(kEpThreads), lds_c, st, ea);
+            if (cons_wpo == 2) hipLaunchKernelGGL((epnp_consensus_kernel<T, 2>), dim3(a.B), dim3(128), lds_c, st, ea);
+            else hipLaunchKernelGGL((epnp_consensus_kernel<T, 4>), dim3(a.B), dim3(256), lds_c, st, ea);
         }
         hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);      // (8 / 4 / 2 quads per wave: 67 / 68 / 102 us against 55 us)
         if (!(a.flags & MR_EPNP_DEFER_REFIT))                  // else: the LM launch carries it (mr_pnp_uncert_from_epnp_grouped)
