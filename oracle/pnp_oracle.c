@@ -960,7 +960,7 @@ static int orc_epnp_init(const float *x2d, const float *x3d, uint8_t *mask, int 
         int ninl = 0; if (ok) for (int i = 0; i < n; ++i) ninl += rm[i];
         if (ok && ninl > 4) { for (int i = 0; i < n; ++i) mask[idx[i]] = rm[i]; n = ninl; }
     } else if (n >= 4) {
-        epnp_solve(o, im, n, K[0], K[4], K[2], K[5], R, tvec, 0); epnp_rodrigues_to_vec(R, rvec); ok = 1;
+        epnp_solve(o, im, n, K[0], K[4], K[2], K[5], R, tvec, 0, 1); epnp_rodrigues_to_vec(R, rvec); ok = 1;
     } else ok = 0;
     if (ok) { init_pose[0] = rvec[1]; init_pose[1] = tvec[0]; init_pose[2] = tvec[1]; init_pose[3] = tvec[2];
               ok = isfinite(init_pose[0]) && isfinite(init_pose[1]) && isfinite(init_pose[2]) && isfinite(init_pose[3]); }
