@@ -1061,6 +1061,27 @@ def head_to_pose_reference(torch, syn, dev, n_batches=4):
         el = time.perf_counter() - t0
         out[name] = {'value': B_PER_GPU * n / el, 'unit': 'solves/s', 'us_per_call': el / n * 1e6, 'launches_in_flight': pipe.depth}
     out['valid_fraction'] = float(ls[0].out['ret_val'].float().mean().item())
+    # launch sets (PoseFromHeadGroupLaunch): four sets of four calls on four streams — sixteen launch objects with their own decoded maps
+    # and outputs over the four resident head outputs
+    from monorun_amd.pose_head import PoseFromHeadGroupLaunch
+    inp = [l.inputs for l in ls]
+    more = [PoseFromHeadLaunch(head, inp[i % n_batches]['all_pred'], inp[i % n_batches]['labels'], False, inp[i % n_batches]['dim'], None, inp[i % n_batches]['rois'],
+                               inp[i % n_batches]['cam_intrinsic'], (syn.IMG_H, syn.IMG_W)) for i in range(12)]
+    allc = ls + more
+    sets = [PoseFromHeadGroupLaunch(allc[4 * k:4 * k + 4]) for k in range(4)]
+    pipe = PnPPipeline(dev, depth=4, record_events=False)
+    for k in range(8):
+        pipe.submit(sets[k % 4], slot=k % 4)
+    pipe.drain()
+    ns = 24
+    t0 = time.perf_counter()
+    for k in range(ns):
+        pipe.submit(sets[k % 4], slot=k % 4)
+    pipe.drain()
+    el = time.perf_counter() - t0
+    same = all(bool(torch.equal(allc[4 + j].out['pose'], ls[j].out['pose']) and torch.equal(allc[4 + j].out['pose_cov_calib'], ls[j].out['pose_cov_calib'])) for j in range(4))
+    out['in_flight_launch_sets'] = {'value': B_PER_GPU * 4 * ns / el, 'unit': 'solves/s', 'us_per_call': el / (4 * ns) * 1e6, 'launches_in_flight': pipe.depth,
+                                    'calls_per_launch_set': 4, 'equal_the_calls_one_by_one': same}
     return out
 
 

@@ -603,12 +603,7 @@ class PoseFromHeadLaunch:
                 ts = torch.cuda.ExternalStream(stream, device=self.dev) if stream is not None else torch.cuda.current_stream(self.dev)
                 e['k2'].run(ts.cuda_stream)
                 e['ep'].run(ts.cuda_stream)
-                with torch.cuda.stream(ts):
-                    o = self.out
-                    s_ = torch.exp(e['logscale'])
-                    torch.mul(o['pose_cov_pred'], s_ * s_[:, None], out=o['pose_cov_calib'])                  # (s s^T) * cov   (uncert_prop_pnp_optimizer.py:96-97)
-                    if e['sd'] > 0.0:                                                                       # cov_correction  (monorun_roi_head.py:530-534)
-                        o['pose_cov_calib'].mul_((e['sd'] / torch.norm(o['t_vec_pred'], p=2, dim=1)).square().view(-1, 1, 1))
+                self._calibrate(ts)
         elif self.B:
             with torch.cuda.device(self.dev):
                 st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
@@ -616,6 +611,15 @@ class PoseFromHeadLaunch:
                 if code:
                     _lib.check(code)
         return self.out
+
+    def _calibrate(self, ts):
+        """reference flow: calibration / distance correction of the covariance on torch stream `ts`, behind the LM launch"""
+        e, o = self._epnp, self.out
+        with torch.cuda.stream(ts):
+            s_ = torch.exp(e['logscale'])
+            torch.mul(o['pose_cov_pred'], s_ * s_[:, None], out=o['pose_cov_calib'])                  # (s s^T) * cov   (uncert_prop_pnp_optimizer.py:96-97)
+            if e['sd'] > 0.0:                                                                       # cov_correction  (monorun_roi_head.py:530-534)
+                o['pose_cov_calib'].mul_((e['sd'] / torch.norm(o['t_vec_pred'], p=2, dim=1)).square().view(-1, 1, 1))
 
     def capture(self):
         """Record the launch into a HIP graph (one warm-up launch first: the LDS opt-in of the kernel is set outside the capture)."""
@@ -634,3 +638,31 @@ class PoseFromHeadLaunch:
         with torch.cuda.device(self.dev):
             self.graph.replay()
         return self.out
+
+
+class PoseFromHeadGroupLaunch:
+    """Up to eight prepared ``PoseFromHeadLaunch`` objects of the REFERENCE flow (heads built with the default initialiser) and the same
+    shape as ONE launch set: every member's K2 decode, then the initialiser's launches and the re-fit / LM launch over the objects of all
+    members (``PnPEpnpGroupLaunch``), then every member's calibration — all on the stream ``run`` is given.  Members keep their inputs
+    and outputs; results are bit-identical to running them one by one.  The regime a serving loop with several images' proposals at
+    hand wants (the stages are latency chains, HIP runs the launches of four streams side by side)."""
+
+    def __init__(self, launches):
+        from .ops.least_squares.pnp_uncert import PnPEpnpGroupLaunch
+        self.members = list(launches)
+        if not self.members or any(m._epnp is None for m in self.members):
+            raise ValueError("PoseFromHeadGroupLaunch groups launches of the reference flow (pnp.initialiser='epnp', the default)")
+        self.dev = self.members[0].dev
+        self.set = PnPEpnpGroupLaunch([m._epnp['ep'] for m in self.members])
+
+    def run(self, stream=None):
+        with torch.cuda.device(self.dev):
+            ts = torch.cuda.ExternalStream(stream, device=self.dev) if stream is not None else torch.cuda.current_stream(self.dev)
+            for m in self.members:
+                if m.B:
+                    m._epnp['k2'].run(ts.cuda_stream)
+            self.set.run(ts.cuda_stream)
+            for m in self.members:
+                if m.B:
+                    m._calibrate(ts)
+        return [m.out for m in self.members]

@@ -5,7 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn
-from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_epnp_device
 from oracle import oracle as orc
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(int(os.environ.get('SEED', 0)))
@@ -34,8 +34,8 @@ for trial in range(int(os.environ.get('TRIALS', 40))):
     with np.errstate(all='ignore'):
         ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_init=True, num_threads=0)
     d = [dv(x2d), dv(istd), dv(x3d), dv(K), dv(ur), dv(vr), dv(thr)]
-    ini, im, iv, _, _ = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[6])
-    out = pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, im, iv, z_min=0.5, inlier_opt_only=True, with_diag=True)
+    out = pnp_uncert_epnp_device(d[0], d[1], d[2], d[3], d[4], d[5], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=d[6], inlier_opt_only=True, with_diag=True)
+    ini, iv = out[6], out[7]
     torch.cuda.synchronize()
     valid, pose, mask = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy(), out[4].cpu().numpy().astype(bool)
     nobj += B

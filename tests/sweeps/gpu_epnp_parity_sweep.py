@@ -7,7 +7,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from monorun_amd import synthetic as syn
-from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device, pnp_uncert_from_init_device
+from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_epnp_device
 from oracle import oracle as orc
 dev = torch.device('cuda:0')
 def dv(a):
@@ -32,11 +32,12 @@ for seed in range(100, 100 + nseeds):
     h = (lambda t: t.to(torch.float16)) if half else (lambda t: t)
     d = [h(dv(x2d)), h(dv(istd)), h(dv(x3d)), dv(K), dv(ur), dv(vr), dv(thr)]
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    ini, im, iv, _, _ = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[6])
-    out = pnp_uncert_from_init_device(d[0], d[1], d[2], d[3], d[4], d[5], ini, im, iv, z_min=0.5, inlier_opt_only=True, with_diag=True,
-                                      flags=int(os.environ.get('WPO', 0)) << 8)      # WPO: waves per object of the LM launch (0 = the library's choice)
+    # the boundary's default path: the initialiser's six launches + the LM launch that carries its re-fit (mr_pnp_uncert_from_epnp_grouped)
+    out = pnp_uncert_epnp_device(d[0], d[1], d[2], d[3], d[4], d[5], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=d[6], inlier_opt_only=True, with_diag=True,
+                                 flags=int(os.environ.get('WPO', 0)) << 8)           # WPO: waves per object of the LM launch (0 = the library's choice)
     torch.cuda.synchronize(); t_gpu += time.perf_counter() - t0
-    valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out]
+    ini, iv = out[6], out[7]
+    valid, pose, cov, tr, mask, diag = [t.cpu().numpy() for t in out[:6]]
     r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag, r_init = ref
     init_ok = r_diag[:, 2] != 8                       # 8 = the initialiser failed
     mm = (mask.astype(bool) != r_mask).any(1)

@@ -534,6 +534,20 @@ def test_head_built_with_the_reference_initialiser_is_honoured_everywhere(dev, o
     out['pose'].zero_(); out['pose_cov_calib'].zero_(); out['inlier_mask_u8'].zero_()
     pl.replay(); torch.cuda.synchronize()
     assert all(torch.equal(out[k], keep[k]) for k in keep)
+    # ... as one launch set with other images' proposals (PoseFromHeadGroupLaunch: K2 per member, the initialiser's launches and the re-fit / LM
+    # launch over the objects of all members, calibration per member): every member's outputs equal its own launch's, bit for bit
+    from monorun_amd.pose_head import PoseFromHeadGroupLaunch
+    b2 = syn.make_batch(B=96, seed=42)
+    ap2, dim2 = syn.encode_head_outputs(b2, seed=42)
+    args2 = (t(ap2), t(b2['labels']), False, t(dim2), None, t(b2['rois']), t(b2['K']), (syn.IMG_H, syn.IMG_W, 3))
+    solo2 = PoseFromHeadLaunch(head, *args2); solo2.run(); torch.cuda.synchronize()
+    members = [PoseFromHeadLaunch(head, *args), PoseFromHeadLaunch(head, *args2), PoseFromHeadLaunch(head, *args)]
+    outs = PoseFromHeadGroupLaunch(members).run(); torch.cuda.synchronize()
+    for o, r in zip(outs, (out, solo2.out, out)):
+        for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'pose_cov_calib', 'inlier_mask', 'dimensions_pred'):
+            assert torch.equal(o[k], r[k]), k
+    with pytest.raises(ValueError):
+        PoseFromHeadGroupLaunch([PoseFromHeadLaunch(UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, initialiser='k0')).to(dev), *args)])
     # ... and the numpy-level driver the reference's flow is written in
     rr = u2d_pnp_cpu(x2d, istd, x3d, b['K'], ur, vr, 0.5, 0.6, thr, True)
     assert np.array_equal(rr[0], ref[0]) and np.array_equal(rr[5], ref[5])
