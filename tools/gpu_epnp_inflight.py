@@ -13,7 +13,7 @@ tag = os.environ.get('MR_PNP_SO', 'default').split('/')[-1] + f' objects={BO} gr
 for depth in [int(v) for v in os.environ.get('DEPTHS', '1,4').split(',')]:
     pipe = PnPPipeline(dev, depth=depth, record_events=False)
     le = [PnPEpnpLaunch(*batches[i % NB][:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=batches[i % NB][6], inlier_opt_only=True,
-                        flags=pipe.flags_for(BO, 784) if depth > 1 else 0) for i in range(max(depth, NB))]
+                        flags=(int(os.environ['LMWPO']) << 8) if 'LMWPO' in os.environ else (pipe.flags_for(BO, 784) if depth > 1 else 0)) for i in range(max(depth, NB))]
     G = int(os.environ.get('GROUP', 1))                # calls per launch set (PnPEpnpGroupLaunch)
     calls = le
     if G > 1:
