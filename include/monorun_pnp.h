@@ -226,7 +226,10 @@ int mr_pnp_uncert_from_init_grouped(
  * (B) u8 and epnp_diag (B,4) f32 (array or entries NULL: none) are OUTPUTS here, with the values mr_epnp_ransac_* would have written;
  * init_mask is the initialiser's.  workspace = the one given to mr_epnp_ransac_* (same B, P, ncalls), untouched in between.  One launch,
  * one pass over the correspondences and one workgroup residency less per call than the two entry points one after the other; results
- * identical, bit for bit.
+ * identical, bit for bit.  cov_calib (array of ncalls (B,16) f32 outputs, or NULL / all entries NULL: none) receives the calibrated and
+ * distance-corrected covariance of mr_pnp_from_head_batched's epilogue: (s s^T) * cov with s = exp(cov_calib_logscale[0..3]) (device
+ * pointer, read at run time; uncert_prop_pnp_optimizer.py:96-97), times (cov_corr_sd / ||t||)^2 when cov_corr_sd > 0
+ * (monorun_roi_head.py:530-534) — float32, the torch operation order.
  */
 int mr_pnp_uncert_from_epnp_grouped(
     int ncalls, const void *const *x2d, const int64_t *x2d_strides, const void *const *istd, const int64_t *istd_strides,
@@ -235,6 +238,7 @@ int mr_pnp_uncert_from_epnp_grouped(
     double *const *init_pose, const uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *epnp_diag, int B, int P,
     float z_min, int inlier_opt_only, int flags,
     uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag,
+    const float *cov_calib_logscale, float cov_corr_sd, float *const *cov_calib,
     const void *workspace, size_t workspace_bytes, void *stream);
 
 /*

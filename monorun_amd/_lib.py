@@ -92,7 +92,7 @@ def load():
                                                     vp, vp, vp, vp, vp, vp, vp]
     lib.mr_pnp_uncert_from_epnp_grouped.restype = i32
     lib.mr_pnp_uncert_from_epnp_grouped.argtypes = [i32, vp, i64p, vp, i64p, vp, i64p, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, i32,
-                                                    vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+                                                    vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, ctypes.c_size_t, vp]
     lib.mr_cov_symeig_rule.restype = i32
     lib.mr_cov_symeig_rule.argtypes = [vp, vp, i32, vp, vp]
     lib.mr_pnp_exact_hessian_batched.restype = i32

@@ -586,7 +586,7 @@ struct PnpCallTable {
     struct CallPtrs {
         const void *x2d, *istd, *x3d, *K, *ur, *vr;
         const double *init_pose; const uint8_t *init_mask, *init_valid;
-        uint8_t *valid; float *pose, *cov, *tr; uint8_t *mask; float *diag;
+        uint8_t *valid; float *pose, *cov, *tr; uint8_t *mask; float *diag; float *cov_calib;
     } call[8];          // = kEpMaxGroup
 };
 
@@ -1158,7 +1158,7 @@ static int pnp_uncert_launch(
     const float *ransac_thr, const double *init_pose, const uint8_t *init_mask, const uint8_t *init_valid, int B, int P,
     float z_min, float istd_thres, int inlier_opt_only, int flags,
     uint8_t *valid, float *pose, float *cov, float *tr_radius, uint8_t *inlier_mask, float *diag, void *stream,
-    int ncalls = 1, const PnpCallTable::CallPtrs *calls = nullptr, const EpnpRefitIn *rf = nullptr) {
+    int ncalls = 1, const PnpCallTable::CallPtrs *calls = nullptr, const EpnpRefitIn *rf = nullptr, const float *calib_logscale = nullptr, float corr_sd = 0.0f) {
     if (B < 0 || P < 4 || P > 64 * kMaxChunks) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range ||
@@ -1175,6 +1175,7 @@ static int pnp_uncert_launch(
     a.B = B; a.P = P; a.z_min = (double)z_min; a.istd_thres = istd_thres; a.inlier_opt_only = inlier_opt_only; a.flags = flags;
     a.valid = valid; a.pose = pose; a.cov = cov; a.tr = tr_radius; a.mask = inlier_mask; a.diag = diag;
     a.stamps = g_stamps;
+    if (calib_logscale && calls && calls[0].cov_calib) { a.calib_logscale = calib_logscale; a.corr_sd = corr_sd; a.cov_calib = calls[0].cov_calib; }      // per call: the table's
     int mm = flags & MR_MEAN_MASK;
     if (mm == MR_MEAN_AUTO) mm = (istd_strides[1] == 1 && P > 1) ? MR_MEAN_PAIRWISE : MR_MEAN_SEQUENTIAL;
     a.mean_mode = mm;
@@ -1231,8 +1232,10 @@ static int pnp_from_init_grouped(
     const double *const *init_pose, const uint8_t *const *init_mask, const uint8_t *const *init_valid, int B, int P,
     float z_min, int inlier_opt_only, int flags,
     uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag, void *stream,
-    EpnpRefitIn *rf = nullptr, float *const *epnp_diag = nullptr) {
+    EpnpRefitIn *rf = nullptr, float *const *epnp_diag = nullptr, const float *calib_logscale = nullptr, float corr_sd = 0.0f, float *const *cov_calib = nullptr) {
     if (ncalls < 1 || ncalls > 8 || B < 0) return MR_ERR_BAD_ARGUMENT;
+    const bool with_calib = cov_calib && cov_calib[0];
+    if (with_calib && (!calib_logscale || (flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !init_pose || !init_mask || !init_valid ||
         !valid || !pose || !tr_radius || !cov) return MR_ERR_BAD_ARGUMENT;
@@ -1254,11 +1257,13 @@ static int pnp_from_init_grouped(
         q.init_pose = init_pose[c] - o * 4; q.init_mask = init_mask[c] - o * P; q.init_valid = init_valid[c] - o;
         q.valid = valid[c] - o; q.pose = pose[c] - o * 4; q.cov = cov[c] ? cov[c] - o * 16 : nullptr; q.tr = tr_radius[c] - o;
         q.mask = with_mask ? inlier_mask[c] - o * P : nullptr; q.diag = with_diag ? diag[c] - o * 4 : nullptr;
+        if ((cov_calib && cov_calib[c] != nullptr) != with_calib) return MR_ERR_BAD_ARGUMENT;
+        q.cov_calib = with_calib ? cov_calib[c] - o * 16 : nullptr;
         if (rf) rf->diag[c] = (epnp_diag && epnp_diag[c]) ? epnp_diag[c] - o * 4 : nullptr;
     }
     return pnp_uncert_launch(x2d[0], x2d_strides, istd[0], istd_strides, x3d[0], x3d_strides, in_dtype, cam_mats[0], cam_batch, u_range[0], v_range[0], range_batch,
                              nullptr, init_pose[0], init_mask[0], init_valid[0], B, P, z_min, 0.0f, inlier_opt_only, flags,
-                             valid[0], pose[0], cov[0], tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp, rf);
+                             valid[0], pose[0], cov[0], tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp, rf, calib_logscale, corr_sd);
 }
 
 int mr_pnp_uncert_from_init_grouped(
@@ -1279,6 +1284,7 @@ int mr_pnp_uncert_from_epnp_grouped(
     double *const *init_pose, const uint8_t *const *init_mask, uint8_t *const *init_valid, float *const *epnp_diag, int B, int P,
     float z_min, int inlier_opt_only, int flags,
     uint8_t *const *valid, float *const *pose, float *const *cov, float *const *tr_radius, uint8_t *const *inlier_mask, float *const *diag,
+    const float *cov_calib_logscale, float cov_corr_sd, float *const *cov_calib,
     const void *workspace, size_t workspace_bytes, void *stream) {
     if (ncalls < 1 || ncalls > kEpMaxGroup || B < 0 || P < 4) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
@@ -1289,7 +1295,7 @@ int mr_pnp_uncert_from_epnp_grouped(
     rf.B = (long long)B * ncalls;
     return pnp_from_init_grouped(ncalls, x2d, x2d_strides, istd, istd_strides, x3d, x3d_strides, in_dtype, cam_mats, cam_batch, u_range, v_range, range_batch,
                                  (const double *const *)init_pose, init_mask, (const uint8_t *const *)init_valid, B, P, z_min, inlier_opt_only, flags,
-                                 valid, pose, cov, tr_radius, inlier_mask, diag, stream, &rf, epnp_diag);
+                                 valid, pose, cov, tr_radius, inlier_mask, diag, stream, &rf, epnp_diag, cov_calib_logscale, cov_corr_sd, cov_calib);
 }
 
 static int epnp_ransac_launch(

@@ -184,7 +184,7 @@ def pnp_uncert_epnp_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_ran
             _lib.check(lib.mr_pnp_uncert_from_epnp_grouped(
                 1, one(x2d), _strides(x2d), one(istd), _strides(istd), one(x3d), _strides(x3d), _DTYPES[dt], one(cam), cam.shape[0], one(ur), one(vr), ur.shape[0],
                 one(init_pose), one(init_mask), one(init_valid), None, B, P, float(z_min), int(bool(inlier_opt_only)), int(flags),
-                one(valid), one(pose), one(cov), one(tr), one(mask), one(diag), work.data_ptr(), work.numel(), st))
+                one(valid), one(pose), one(cov), one(tr), one(mask), one(diag), None, 0.0, None, work.data_ptr(), work.numel(), st))
     return valid, pose, cov, tr, mask, diag, init_pose, init_valid
 
 
@@ -265,8 +265,11 @@ class PnPEpnpLaunch:
 
     def __init__(self, coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range, z_min=0.5, epnp_istd_thres=0.6,
                  epnp_ransac_thres=None, inlier_opt_only=True, flags=0, max_iters=30, with_diag=False, first_round=None,
-                 out=None, mask=None, work=None, fused=True):
-        """fused (default): the initialiser stops before its last launch (MR_EPNP_DEFER_REFIT) and the LM launch runs the re-fit's pose
+                 out=None, mask=None, work=None, fused=True, calib=None):
+        """calib: None, or (logscale, sd, out) — a float32 device tensor of the four calibration log-scales (read when the launch RUNS), the
+        distance-correction constant (0 = none) and a (B,4,4) float32 tensor that receives (s s^T) * cov * (sd / ||t||)^2, written by the LM
+        launch's epilogue (fused form only; uncert_prop_pnp_optimizer.py:96-97, monorun_roi_head.py:530-534).
+        fused (default): the initialiser stops before its last launch (MR_EPNP_DEFER_REFIT) and the LM launch runs the re-fit's pose
         candidates as its prologue (``mr_pnp_uncert_from_epnp_grouped``: one launch and one pass over the correspondences less; same
         results, bit for bit); False: the two entry points one after the other (``mr_epnp_ransac_batched``, then
         ``mr_pnp_uncert_from_init_batched``).
@@ -312,6 +315,12 @@ class PnPEpnpLaunch:
         self.args_lm = head + [ur.data_ptr(), vr.data_ptr(), ur.shape[0], self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
                                B, P, float(z_min), int(bool(inlier_opt_only)), int(flags), self.valid.data_ptr(), self.pose.data_ptr(), self.cov.data_ptr(),
                                self.tr.data_ptr(), self.mask.data_ptr(), self.diag.data_ptr() if self.diag is not None else None]
+        self.calib = calib
+        if calib is not None:
+            ls, _, co = calib
+            if not fused:
+                raise ValueError('calib needs the fused form (the LM launch that carries the re-fit writes it)')
+            assert ls.dtype == torch.float32 and ls.numel() == 4 and ls.device == dev and co.dtype == torch.float32 and co.is_contiguous() and co.numel() == B * 16
         self.fused = bool(fused)
         if self.fused:
             self._single = PnPEpnpGroupLaunch([self], work=self.work, lm='fused')
@@ -381,7 +390,14 @@ class PnPEpnpGroupLaunch:
         la = self._lm_arrays
         self.args_lm = [n, x2d, al[1], istd, al[3], x3d, al[5], al[6], cam, al[8], la[9], la[10], al[11], la[12], la[13], la[14], f.B, P, al[17], al[18], al[19],
                         la[20], la[21], la[22], la[23], la[24], la[25]]
-        self.args_fused = self.args_lm[:16] + [idiag] + self.args_lm[16:] + [self.work.data_ptr(), self.work.numel()]
+        cal = [getattr(m, 'calib', None) for m in self.members]
+        if any(c is not None for c in cal) and (any(c is None for c in cal) or any(c[0].data_ptr() != cal[0][0].data_ptr() or c[1] != cal[0][1] for c in cal)):
+            raise ValueError('the members of a group must share the calibration (log-scale tensor and distance constant), or have none')
+        if cal[0] is not None and lm != 'fused':
+            raise ValueError("calibrated covariances are written by the 'fused' form")
+        self._calib_arr = (ctypes.c_void_p * n)(*[c[2].data_ptr() for c in cal]) if cal[0] is not None else None
+        self.args_fused = self.args_lm[:16] + [idiag] + self.args_lm[16:] + [cal[0][0].data_ptr() if cal[0] is not None else None, float(cal[0][1]) if cal[0] is not None else 0.0,
+                                                                             self._calib_arr, self.work.data_ptr(), self.work.numel()]
         self._lm_any = []
         for m in self.members:                             # args_lm with MR_ANY_ORDER in its flags (argument 19 of mr_pnp_uncert_from_init_batched)
             a = list(m.args_lm)

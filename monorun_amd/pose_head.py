@@ -549,16 +549,18 @@ class PoseFromHeadLaunch:
             self.inputs['flip'] = k2.inputs['flip']                     # the one input K2 holds a private copy of: refresh THIS tensor
             self.inputs['coord_2d'] = k2.inputs['coord_2d']
             d = k2.out
-            ep = PnPEpnpLaunch(_planar_view(d['coords_2d']), _planar_view(d['coords_2d_istd']), _planar_view(d['coords_3d']), self.inputs['cam_intrinsic'],
-                               ur, vr, z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, epnp_ransac_thres=d['ransac_thr'],
-                               inlier_opt_only=p.inlier_opt_only, flags=flags, first_round=getattr(p, 'epnp_first_round', None))
             # the calibration reads the LIVE parameter on every run / replay (an alias of it when the head lives on the launch device in
             # float32, like the fused launch's): weights loaded or updated in place after this object was built are honoured, also by a
-            # captured graph
-            ls = pose_head.cov_calib_logscale.detach().to(**f32)
-            self._epnp = dict(k2=k2, ep=ep, logscale=ls, sd=float(ref_length * ref_focal_y * target_std) if apply_cov_correction else 0.0)
+            # captured graph.  It is the LM launch's epilogue (mr_pnp_uncert_from_epnp_grouped: cov_calib), like the one-launch kernel's.
+            ls = pose_head.cov_calib_logscale.detach().to(**f32).contiguous()
+            sdc = float(ref_length * ref_focal_y * target_std) if apply_cov_correction else 0.0
+            cov_calib = torch.empty(B, 4, 4, **f32)
+            ep = PnPEpnpLaunch(_planar_view(d['coords_2d']), _planar_view(d['coords_2d_istd']), _planar_view(d['coords_3d']), self.inputs['cam_intrinsic'],
+                               ur, vr, z_min=p.z_min, epnp_istd_thres=p.epnp_istd_thres, epnp_ransac_thres=d['ransac_thr'],
+                               inlier_opt_only=p.inlier_opt_only, flags=flags, first_round=getattr(p, 'epnp_first_round', None), calib=(ls, sdc, cov_calib))
+            self._epnp = dict(k2=k2, ep=ep, logscale=ls, sd=sdc)
             self.out = dict(ret_val_u8=ep.valid, pose=ep.pose, pose_cov_pred=ep.cov, tr_radius=ep.tr, inlier_mask_u8=ep.mask,
-                            dimensions_pred=d['dims'], dimensions_var=d['dims_var'], pose_cov_calib=torch.empty(B, 4, 4, **f32))
+                            dimensions_pred=d['dims'], dimensions_var=d['dims_var'], pose_cov_calib=cov_calib)
             o = self.out
             o['ret_val'], o['inlier_mask'] = o['ret_val_u8'].view(torch.bool), o['inlier_mask_u8'].view(torch.bool)
             o['yaw_pred'], o['t_vec_pred'] = o['pose'][:, :1], o['pose'][:, 1:]
@@ -602,8 +604,7 @@ class PoseFromHeadLaunch:
             with torch.cuda.device(self.dev):
                 ts = torch.cuda.ExternalStream(stream, device=self.dev) if stream is not None else torch.cuda.current_stream(self.dev)
                 e['k2'].run(ts.cuda_stream)
-                e['ep'].run(ts.cuda_stream)
-                self._calibrate(ts)
+                e['ep'].run(ts.cuda_stream)                # (calibration / distance correction: the LM launch's epilogue)
         elif self.B:
             with torch.cuda.device(self.dev):
                 st = stream if stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
@@ -611,15 +612,6 @@ class PoseFromHeadLaunch:
                 if code:
                     _lib.check(code)
         return self.out
-
-    def _calibrate(self, ts):
-        """reference flow: calibration / distance correction of the covariance on torch stream `ts`, behind the LM launch"""
-        e, o = self._epnp, self.out
-        with torch.cuda.stream(ts):
-            s_ = torch.exp(e['logscale'])
-            torch.mul(o['pose_cov_pred'], s_ * s_[:, None], out=o['pose_cov_calib'])                  # (s s^T) * cov   (uncert_prop_pnp_optimizer.py:96-97)
-            if e['sd'] > 0.0:                                                                       # cov_correction  (monorun_roi_head.py:530-534)
-                o['pose_cov_calib'].mul_((e['sd'] / torch.norm(o['t_vec_pred'], p=2, dim=1)).square().view(-1, 1, 1))
 
     def capture(self):
         """Record the launch into a HIP graph (one warm-up launch first: the LDS opt-in of the kernel is set outside the capture)."""
@@ -643,7 +635,7 @@ class PoseFromHeadLaunch:
 class PoseFromHeadGroupLaunch:
     """Up to eight prepared ``PoseFromHeadLaunch`` objects of the REFERENCE flow (heads built with the default initialiser) and the same
     shape as ONE launch set: every member's K2 decode, then the initialiser's launches and the re-fit / LM launch over the objects of all
-    members (``PnPEpnpGroupLaunch``), then every member's calibration — all on the stream ``run`` is given.  Members keep their inputs
+    members (``PnPEpnpGroupLaunch``; calibration in its epilogue) — all on the stream ``run`` is given.  Members keep their inputs
     and outputs; results are bit-identical to running them one by one.  The regime a serving loop with several images' proposals at
     hand wants (the stages are latency chains, HIP runs the launches of four streams side by side)."""
 
@@ -662,7 +654,4 @@ class PoseFromHeadGroupLaunch:
                 if m.B:
                     m._epnp['k2'].run(ts.cuda_stream)
             self.set.run(ts.cuda_stream)
-            for m in self.members:
-                if m.B:
-                    m._calibrate(ts)
         return [m.out for m in self.members]

@@ -529,7 +529,7 @@ def test_head_built_with_the_reference_initialiser_is_honoured_everywhere(dev, o
     check(out, 'PoseFromHeadLaunch.run')
     for k in ('ret_val', 'yaw_pred', 't_vec_pred', 'pose_cov_pred', 'inlier_mask', 'dimensions_pred'):
         assert torch.equal(out[k], r_f[k]), k
-    assert torch.allclose(out['pose_cov_calib'], r_f['pose_cov_calib'], rtol=1e-6, atol=0)
+    assert torch.allclose(out['pose_cov_calib'][out['ret_val']], r_f['pose_cov_calib'][out['ret_val']], rtol=2e-6, atol=0)      # expf in the kernel's epilogue, torch.exp in the module path
     keep = {k: out[k].clone() for k in ('pose', 'pose_cov_calib', 'inlier_mask_u8')}
     out['pose'].zero_(); out['pose_cov_calib'].zero_(); out['inlier_mask_u8'].zero_()
     pl.replay(); torch.cuda.synchronize()

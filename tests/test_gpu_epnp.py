@@ -463,7 +463,7 @@ def test_refit_inside_the_lm_launch_equals_the_two_entry_points(dev):
     outs = [torch.empty(32, device=dev, dtype=torch.uint8), torch.empty(32, 4, device=dev), torch.empty(32, 16, device=dev), torch.empty(32, device=dev), torch.empty(32, x[0].shape[1], device=dev, dtype=torch.uint8)]
     def lm(ncalls=1, wptr=work.data_ptr(), wbytes=work.numel()):
         return lib.mr_pnp_uncert_from_epnp_grouped(ncalls, one(x[0]), st(x[0]), one(x[1]), st(x[1]), one(x[2]), st(x[2]), 0, one(x[3]), 1, one(x[4]), one(x[5]), 1,
-                                                   one(ip), one(im), one(iv), None, 32, x[0].shape[1], 0.5, 1, 0, *[one(o) for o in outs], one(None), wptr, wbytes, None)
+                                                   one(ip), one(im), one(iv), None, 32, x[0].shape[1], 0.5, 1, 0, *[one(o) for o in outs], one(None), None, 0.0, None, wptr, wbytes, None)
     assert lm(ncalls=0) == -1 and lm(ncalls=9) == -1 and lm(wptr=None) == -1 and lm(wbytes=work.numel() - 1) == -1
     torch.cuda.synchronize()
 
