@@ -373,10 +373,17 @@ def run(args):
                 return
             bi0, sl0 = self.pend[0]
             n = len(self.pend)
-            ev = self.pipe.submit(group_of(self.launches, bi0, sl0, n) if n > 1 else self.launches[bi0][sl0], slot=sl0 // self.lg if self.lg > 1 else sl0)
             pend, self.pend = self.pend, []
-            for _, sl in pend:
-                self.evs[sl] = ev
+            if n > 1 and sl0 % self.lg == 0:
+                ev = self.pipe.submit(group_of(self.launches, bi0, sl0, n), slot=sl0 // self.lg)
+                for _, sl in pend:
+                    self.evs[sl] = ev
+            else:
+                # one call, or a set that does not start on a set boundary (stepping went on after a fence in the middle of a set: only the
+                # workspace of a set's FIRST slot is sized for a whole set): the calls one by one, each with its own slot's
+                # workspace, on the stream their set would have used
+                for bi, sl in pend:
+                    self.evs[sl] = self.pipe.submit(self.launches[bi][sl], slot=sl // self.lg if self.lg > 1 else sl)
             for _, sl in pend:
                 self._after(sl)
 
@@ -598,6 +605,11 @@ def run(args):
             extra['head_to_pose_1024_reference_flow'] = head_to_pose_reference(torch, syn, dev)
         except Exception as e:                                          # noqa: BLE001 — secondary figure
             extra['head_to_pose_1024_reference_flow'] = {'error': repr(e)}
+        # the regime the pipeline runs (one image, <= 100 proposals, one call at a time) through the DEFAULT flow
+        try:
+            extra['per_image_B100_reference_flow'] = per_image_latency(torch, syn, dev, batch0, args, reference_flow=True)
+        except Exception as e:                                          # noqa: BLE001 — secondary figure
+            extra['per_image_B100_reference_flow'] = {'error': repr(e)}
     # reference flow: how one call splits into the initialiser's launches and the LM launch (HIP events on the launch stream, every batch)
     split = None
     if ref_flow:
@@ -620,17 +632,20 @@ def run(args):
         achieved = BYTES_PER_SOLVE * B_PER_GPU / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src, traffic_iso = None, None, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # HBM bytes per launch from the PMC passes (see profiles/README.md)
-        if ref_flow and not stress:
-            for tname in ('r05_epnp_traffic.json', 'r04_epnp_traffic.json'):
-                tf = os.path.join(ROOT, 'profiles', tname)
-                if os.path.exists(tf):
-                    try:
-                        tj = json.load(open(tf))
-                        traffic = traffic_iso = tj.get('hbm_bytes_per_call')
-                        traffic_src = f'profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over all launches of one call, committed); replayed, not measured in this run'
-                        break
-                    except Exception:  # noqa: BLE001
-                        pass
+        def newest(pattern):                     # the newest committed profile of this name (profiles/rNN_<pattern>), or None
+            import glob
+            c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_' + pattern)), reverse=True)
+            return c[0] if c else None
+        if ref_flow:
+            tf = newest('epnp_traffic_stress.json' if stress else 'epnp_traffic.json')
+            if tf:
+                try:
+                    tj = json.load(open(tf))
+                    traffic = traffic_iso = tj.get('hbm_bytes_per_call')
+                    traffic_src = (f'profiles/{os.path.basename(tf)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over all launches of one call, one call at a time, committed; '
+                                   f'{tj.get("ratio_traffic_over_algorithmic", 0):.2f} x the algorithmic bytes); replayed, not measured in this run')
+                except Exception:  # noqa: BLE001
+                    traffic = traffic_iso = None
         elif os.path.exists(tfile) and not stress:
             try:
                 tj = json.load(open(tfile))
@@ -643,6 +658,18 @@ def run(args):
             except Exception:  # noqa: BLE001
                 traffic = None
         valu = None
+        if ref_flow and not stress:
+            vf = newest('epnp_valu_per_launch.json')
+            if vf:
+                try:
+                    vj = json.load(open(vf))
+                    cnt = float(vj['valu_insts_per_call'])
+                    t_min = cnt * 4.0 / (1024 * 2.4e9)
+                    valu = {'valu_insts_per_call': cnt, 'min_issue_time_us_at_4_cycles': t_min * 1e6, 'frac_of_call_time': t_min / (kernel_ms * 1e-3),
+                            'per_launch': vj.get('per_launch'),
+                            'source': f'profiles/{os.path.basename(vf)} (rocprofv3 --pmc SQ_INSTS_VALU over the launches of one call, one call at a time, committed); replayed, not measured in this run'}
+                except Exception:  # noqa: BLE001
+                    valu = None
         for sname in ('r04_summary.json', 'r03_summary.json', 'r02_summary.json', 'r01_summary.json'):           # PMC instruction counts of the same command
             sfile = os.path.join(ROOT, 'profiles', sname)
             if os.path.exists(sfile) and not stress and not ref_flow:
@@ -753,7 +780,8 @@ def run(args):
                 'what': "`value` IS this flow since round 5: cv2.solvePnPRansac(EPNP, 30 iterations) restated on the GPU, then the LM + covariance — what PnPUncert built from the "
                         "reference's own config dict runs (INTEGRATION.md section 2); the one-launch K0 path is the explicit fast mode (`k0_fast_mode`)",
                 'in_flight': {'value': line['value'], 'unit': 'solves/s', 'launches_in_flight': L, 'calls_per_launch_set': LG, 'steady_state': ss['value']},
-                'one_call_at_a_time': one, 'launch_split': split}
+                'one_call_at_a_time': one, 'launch_split': split,
+                'per_image_B100': extra.pop('per_image_B100_reference_flow', None)}
             if split is not None:
                 # the longest launch of the call: the LM launch (its length is its slowest object's: up to 35 LM iterations from EPnP starts)
                 ach = BYTES_PER_SOLVE * B_PER_GPU / (split['lm_launch_ms'] * 1e-3) / 1e9
@@ -1155,15 +1183,20 @@ def head_to_pose(torch, syn, PnPLaunch, dev, n_batches=4):
     }
 
 
-def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):
-    """B = 100 proposals of one image: raw NOC-head output -> pose dict through the Python API (pose_from_head, fused: one
-    launch incl. decode, calibration, distance correction), eagerly, through a prepared launch (PoseFromHeadLaunch: arguments built
-    once over static buffers) and as a HIP-graph replay of that launch.  wall_us_per_call_synced = host wall time per call with a
-    stream synchronise after every call (what a per-image pipeline sees); issue_us_per_call = back-to-back enqueue cost."""
+def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300, reference_flow=False):
+    """B = 100 proposals of one image (monorun_roi_head.py:452: one image per forward; configs/kitti_car.py:200: max_per_img = 100): raw
+    NOC-head output -> pose dict through the Python API (pose_from_head), eagerly, through a prepared launch (PoseFromHeadLaunch: arguments
+    built once over static buffers) and as a HIP-graph replay of that launch.  reference_flow=False: the fast mode's head (ONE launch incl.
+    decode, calibration, distance correction); True: the head as the reference's config dict builds it (K2 decode + the initialiser's launches +
+    the re-fit / LM launch, monorun_roi_head.py:509-534).  wall_us_per_call_synced = host wall time per call with a stream synchronise after
+    every call (what a per-image pipeline sees); issue_us_per_call = back-to-back enqueue cost."""
     from monorun_amd.pose_head import UncertPropPnPOptimizer, pose_from_head
     sub = {k: (v[:n_obj] if isinstance(v, np.ndarray) and v.shape[:1] == (batch0['labels'].shape[0],) else v) for k, v in batch0.items()}
     all_pred, dim = syn.encode_head_outputs(sub, seed=SEED)
-    head = UncertPropPnPOptimizer(pnp=dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False, initialiser='k0')).to(dev)      # the fast mode's one-launch head -> pose path
+    pnp_cfg = dict(type='PnPUncert', z_min=0.5, epnp_istd_thres=0.6, inlier_opt_only=True, forward_exact_hessian=False)      # configs/kitti_car.py:118-123
+    if not reference_flow:
+        pnp_cfg['initialiser'] = 'k0'                                   # the fast mode's one-launch head -> pose path
+    head = UncertPropPnPOptimizer(pnp=pnp_cfg).to(dev)
     ap, lab, dm, rois = torch.from_numpy(all_pred).to(dev), torch.from_numpy(sub['labels']).to(dev), torch.from_numpy(dim).to(dev), torch.from_numpy(sub['rois']).to(dev)
     K = torch.from_numpy(sub['K']).to(dev)
     out = {}
@@ -1205,6 +1238,13 @@ def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300):
         assert torch.equal(ref[k], prepared.out[k]) and torch.equal(ref[k], graph.out[k]), k
     out['objects'] = n_obj
     out['valid'] = int(ref['ret_val'].sum().item())
+    out['outputs_of_the_three_paths_equal'] = True
+    # GPU time of one call: HIP events on the launch stream around prepared launches issued one at a time
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+    for e0, e1 in evs:
+        e0.record(); prepared.run(); e1.record()
+    torch.cuda.synchronize()
+    out['gpu_us_per_call_hip_events'] = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]) * 1e3)
     return out
 
 

@@ -70,7 +70,7 @@ extern "C" {
 #define MR_LM_MAXIT_SHIFT      16      /* bits 16..21: Ceres' max_num_iterations for the LM (0 = the default, 50; 1..63) */
 #define MR_LM_MAXIT_MASK       (0x3F << MR_LM_MAXIT_SHIFT)
 #define MR_EPNP_FIRST_ROUND_SHIFT 24   /* mr_epnp_ransac_batched, bits 24..28: hypotheses solved for EVERY object before the replayed RANSAC loop
-                                          is consulted (1..30; 0 = the default: 8 for launch sets of fewer than 2048 objects, 3 beyond); the rest are solved only for the objects whose loop still
+                                          is consulted (1..30; 0 = the default: 10 for launch sets of fewer than 2048 objects, 3 beyond); the rest are solved only for the objects whose loop still
                                           wants iterations.  Changes the work done, never the result */
 #define MR_EPNP_FIRST_ROUND_MASK  (0x1F << MR_EPNP_FIRST_ROUND_SHIFT)
 #define MR_EPNP_REFIT_F32   0x40      /* mr_epnp_ransac_batched: normalise the image points of solvePnPRansac's final re-fit in float32 (round 3's

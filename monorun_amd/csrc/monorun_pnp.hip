@@ -1238,14 +1238,15 @@ static int pnp_from_init_grouped(
     if (with_calib && (!calib_logscale || (flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
     if (!x2d || !istd || !x3d || !x2d_strides || !istd_strides || !x3d_strides || !cam_mats || !u_range || !v_range || !init_pose || !init_mask || !init_valid ||
-        !valid || !pose || !tr_radius || !cov) return MR_ERR_BAD_ARGUMENT;
+        !valid || !pose || !tr_radius || (!cov && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;       // (no covariance asked: the table itself may be NULL, like its entries)
+    if ((long long)B * ncalls > 0x7fffffffll / kEpMaxIters) return MR_ERR_UNSUPPORTED;                         // objects are numbered through the set in int arithmetic (as in epnp_ransac_launch)
     const bool with_mask = inlier_mask && inlier_mask[0], with_diag = diag && diag[0];
     const size_t esize = in_dtype == MR_F64 ? 8 : (in_dtype == MR_F32 ? 4 : 2);
     const long long ks = (cam_batch == 1) ? 0 : 9, rs = (range_batch == 1) ? 0 : 2;
     PnpCallTable::CallPtrs cp[8];
     for (int c = 0; c < ncalls; ++c) {
         if (!x2d[c] || !istd[c] || !x3d[c] || !cam_mats[c] || !u_range[c] || !v_range[c] || !init_pose[c] || !init_mask[c] || !init_valid[c] ||
-            !valid[c] || !pose[c] || !tr_radius[c] || (!cov[c] && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
+            !valid[c] || !pose[c] || !tr_radius[c] || (!(cov && cov[c]) && !(flags & MR_COV_NONE))) return MR_ERR_BAD_ARGUMENT;
         if ((inlier_mask && inlier_mask[c] != nullptr) != with_mask || (diag && diag[c] != nullptr) != with_diag) return MR_ERR_BAD_ARGUMENT;      // all or none
         // pointers biased so that the GLOBAL object index c * B + i addresses object i of call c
         const long long o = (long long)c * B;
@@ -1255,7 +1256,7 @@ static int pnp_from_init_grouped(
         q.x3d = (const char *)x3d[c] - o * x3d_strides[0] * (long long)esize;
         q.K = (const char *)cam_mats[c] - o * ks * 4; q.ur = (const char *)u_range[c] - o * rs * 4; q.vr = (const char *)v_range[c] - o * rs * 4;
         q.init_pose = init_pose[c] - o * 4; q.init_mask = init_mask[c] - o * P; q.init_valid = init_valid[c] - o;
-        q.valid = valid[c] - o; q.pose = pose[c] - o * 4; q.cov = cov[c] ? cov[c] - o * 16 : nullptr; q.tr = tr_radius[c] - o;
+        q.valid = valid[c] - o; q.pose = pose[c] - o * 4; q.cov = (cov && cov[c]) ? cov[c] - o * 16 : nullptr; q.tr = tr_radius[c] - o;
         q.mask = with_mask ? inlier_mask[c] - o * P : nullptr; q.diag = with_diag ? diag[c] - o * 4 : nullptr;
         if ((cov_calib && cov_calib[c] != nullptr) != with_calib) return MR_ERR_BAD_ARGUMENT;
         q.cov_calib = with_calib ? cov_calib[c] - o * 16 : nullptr;
@@ -1263,7 +1264,7 @@ static int pnp_from_init_grouped(
     }
     return pnp_uncert_launch(x2d[0], x2d_strides, istd[0], istd_strides, x3d[0], x3d_strides, in_dtype, cam_mats[0], cam_batch, u_range[0], v_range[0], range_batch,
                              nullptr, init_pose[0], init_mask[0], init_valid[0], B, P, z_min, 0.0f, inlier_opt_only, flags,
-                             valid[0], pose[0], cov[0], tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp, rf, calib_logscale, corr_sd);
+                             valid[0], pose[0], cov ? cov[0] : nullptr, tr_radius[0], with_mask ? inlier_mask[0] : nullptr, with_diag ? diag[0] : nullptr, stream, ncalls, cp, rf, calib_logscale, corr_sd);
 }
 
 int mr_pnp_uncert_from_init_grouped(
@@ -1288,6 +1289,7 @@ int mr_pnp_uncert_from_epnp_grouped(
     const void *workspace, size_t workspace_bytes, void *stream) {
     if (ncalls < 1 || ncalls > kEpMaxGroup || B < 0 || P < 4) return MR_ERR_BAD_ARGUMENT;
     if (B == 0) return MR_OK;
+    if ((long long)B * ncalls > 0x7fffffffll / kEpMaxIters) return MR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < epnp_work_bytes(B * ncalls, P, nullptr, nullptr)) return MR_ERR_BAD_ARGUMENT;
     EpnpRefitIn rf;
     memset(&rf, 0, sizeof rf);
@@ -1348,13 +1350,14 @@ static int epnp_ransac_launch(
     }
     hipStream_t st = (hipStream_t)stream;
     // hypotheses solved for every object before the replayed loop is consulted: MR_EPNP_FIRST_ROUND bits of `flags` (1..30), else the
-    // environment variable MR_EPNP_FIRST_ROUND, else by the size of the launch set: 8 up to 2047 objects (one call at a time: the
-    // second round is a full latency chain, and 8 hypotheses make it idle in 85 % of config-2 batches), 3 beyond (several calls grouped
+    // environment variable MR_EPNP_FIRST_ROUND, else by the size of the launch set: 10 up to 2047 objects (one call at a time: the
+    // second round is a full latency chain; 8 hypotheses make it idle in 85 % of config-2 batches, 10 in 97 %: 278.6 -> 264.1 us per
+    // 1024-object call, 228.9 -> 221.8 at 256, within noise at 100 — profiles/r06_first_round.txt), 3 beyond (several calls grouped
     // or a large batch: the chip is busy, the hypotheses nobody needs are the cost — sets of three calls: 9.6 / 9.9 / 10.3 / 10.3 M solves/s
     // with 6 / 4 / 3 / 2, profiles/r05_epnp_grouped_first_round.txt).  Changes the work, never a result.
     static const int first_env = [] { const char *e = getenv("MR_EPNP_FIRST_ROUND"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > 30 ? 30 : v); }();
     const int first_bits = (flags & MR_EPNP_FIRST_ROUND_MASK) >> MR_EPNP_FIRST_ROUND_SHIFT;
-    const int first_round = first_bits ? (first_bits > 30 ? 30 : first_bits) : (first_env ? first_env : ((long long)B * ncalls >= 2048 ? 3 : 8));
+    const int first_round = first_bits ? (first_bits > 30 ? 30 : first_bits) : (first_env ? first_env : ((long long)B * ncalls >= 2048 ? 3 : 10));
     switch (in_dtype) {
         case MR_F32: return launch_epnp_stages<float>(sa, workspace, workspace_bytes, first_round, st);
         case MR_F16: return launch_epnp_stages<__half>(sa, workspace, workspace_bytes, first_round, st);

@@ -323,7 +323,11 @@ class PnPEpnpLaunch:
             assert ls.dtype == torch.float32 and ls.numel() == 4 and ls.device == dev and co.dtype == torch.float32 and co.is_contiguous() and co.numel() == B * 16
         self.fused = bool(fused)
         if self.fused:
+            # the launch set of this one call.  It keeps argument lists (raw pointers into tensors THIS object owns), not this object: no
+            # reference cycle, so the workspace / outputs / masks (~17 MB per 1024 objects) are freed by refcount when the launch is dropped
+            # — a serving loop that builds launches per request does not wait for the cyclic GC
             self._single = PnPEpnpGroupLaunch([self], work=self.work, lm='fused')
+            self._single.members = ()
 
     def run(self, stream=None):
         if self.B == 0:
@@ -615,7 +619,8 @@ def pnp_uncert(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_range, v_range,
     initialiser inside the fused kernel (one launch, ~5 x the throughput, inlier sets that differ from the reference flow's on ~13 % of
     the objects).
     epnp_first_round (with initialiser='epnp'; not a reference keyword): how many of the 30 speculative RANSAC hypotheses are solved for
-    every object before the replayed loop is consulted (default 8; the rest only where the loop wants them; 30 = one round, the setting
+    every object before the replayed loop is consulted (default: the library's rule — 10 for calls or launch sets of fewer than 2048 objects,
+    3 beyond —; the rest only where the loop wants them; 30 = one round, the setting
     for outlier-heavy candidate sets one call at a time).  Never changes a result.
     cov_symeig_rule (not a reference keyword): also apply, per object, the eigenvalue test of the reference's fallback branch
     (pnp_uncert.py:77-85: keep an object only if lambda_min(h) > max(1e-6 lambda_max(h), 0), else ret_val = False and pose_cov = I).

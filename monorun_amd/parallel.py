@@ -127,33 +127,56 @@ def _rccl():
     return lib
 
 
+def _agree(ok, device, group):
+    """MIN over the ranks of a local outcome (1 = fine), through the job's own c10d group: the ONE kind of collective every rank issues in every
+    phase below, whatever happened to it locally."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
 def agreed_rccl_all_gather(device, group=None):
     """``RcclAllGather(device)`` on EVERY rank or on none: returns (exchange | None, reason | None).
 
     The private communicator is an optimisation (its collective costs ~5 us of host time against ~45 us through c10d); a rank that
-    cannot set it up — library not found, a symbol missing, ncclCommInitRank refusing — must not leave the others waiting inside a
-    collective it will never join.  Every rank therefore reports its own outcome, the job takes the minimum, and if any rank failed
-    all of them drop to ``torch.distributed``'s all-gather (the caller says so in its output).  What this does NOT cover: a bootstrap
-    that hangs instead of failing (then the job's own timeout applies).  Failure modes handled: see DESIGN.md section 8."""
-    ag, why = None, None
-    try:
-        ag = RcclAllGather(device, group)
-        if ag.nranks() != dist.get_world_size(group):
-            why = f'ncclCommCount reports {ag.nranks()} ranks, the job has {dist.get_world_size(group)}'
+    cannot set it up — library not found, a symbol missing, ncclGetUniqueId or ncclCommInitRank refusing — must not leave the others
+    waiting inside a collective it will never join.  The set-up therefore runs in AGREED PHASES, and no rank ever skips a c10d collective
+    another rank issues:
+      1. every rank loads the library, rank 0 also takes the unique id (both inside try); all_reduce(MIN) of the outcomes;
+      2. only if every rank is fine: broadcast of the id (every rank takes part);
+      3. every rank calls ncclCommInitRank and checks ncclCommCount against the job; all_reduce(MIN) again.
+    If any phase fails anywhere, all ranks drop to ``torch.distributed``'s all-gather together (the caller says so in its output).  What this
+    does NOT cover: a bootstrap that hangs instead of failing — e.g. a rank whose ncclCommInitRank returns an error while the others are still
+    inside theirs — (then the job's own timeout applies).  Failure modes handled: see DESIGN.md section 8."""
+    why, lib, uid = None, None, _NcclUniqueId()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    try:                                                         # phase 1: local set-up, nothing collective inside the try
+        lib = _rccl()
+        if rank == 0:
+            rc = lib.ncclGetUniqueId(ctypes.byref(uid))
+            if rc != 0:
+                raise RuntimeError(f'ncclGetUniqueId: RCCL error {rc}: {lib.ncclGetErrorString(rc).decode()}')
     except Exception as e:                                       # noqa: BLE001 — any set-up problem
         why = f'{type(e).__name__}: {e}'
-    ok = torch.tensor([0 if why else 1], dtype=torch.int32, device=device if dist.get_backend(group) == 'nccl' else 'cpu')
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if int(ok.item()) == 1:
+    if not _agree(why is None, device, group):
+        return None, why or 'another rank could not load RCCL / take the unique id for the private communicator'
+    box = [ctypes.string_at(ctypes.byref(uid), 128)]             # phase 2 (every rank is fine, so every rank is here): all 128 raw bytes of the id
+    dist.broadcast_object_list(box, src=0, group=group)
+    ag = None
+    try:                                                         # phase 3: the communicator itself
+        ag = RcclAllGather(device, group, _lib=lib, _uid_bytes=box[0])
+        if ag.nranks() != world:
+            why = f'ncclCommCount reports {ag.nranks()} ranks, the job has {world}'
+    except Exception as e:                                       # noqa: BLE001
+        why = f'{type(e).__name__}: {e}'
+    if _agree(why is None, device, group):
         return ag, None
-    if ag is not None and why is None:
-        why = 'another rank could not set up its private RCCL communicator'
     if ag is not None:
         try:
             ag.close()
         except Exception:                                        # noqa: BLE001
             pass
-    return None, why
+    return None, why or 'another rank could not set up its private RCCL communicator'
 
 
 class RcclAllGather:
@@ -169,16 +192,21 @@ class RcclAllGather:
 
     NCCL_UINT8 = 1
 
-    def __init__(self, device, group=None):
-        self.lib = _rccl()
+    def __init__(self, device, group=None, _lib=None, _uid_bytes=None):
+        """_lib / _uid_bytes: the library handle and the unique id ``agreed_rccl_all_gather`` obtained in its own agreed phases (then nothing
+        collective happens in here before ncclCommInitRank).  Without them the constructor does both itself — a set-up failure on ONE rank
+        then leaves the others inside the broadcast: use ``agreed_rccl_all_gather`` in jobs of more than one rank."""
+        self.lib = _lib if _lib is not None else _rccl()
         self.dev = torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         uid = _NcclUniqueId()
-        if self.rank == 0:
-            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)))
-        box = [ctypes.string_at(ctypes.byref(uid), 128)]            # all 128 raw bytes (a c_char array converts only up to a NUL)
-        dist.broadcast_object_list(box, src=0, group=group)
-        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        if _uid_bytes is None:
+            if self.rank == 0:
+                self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)))
+            box = [ctypes.string_at(ctypes.byref(uid), 128)]        # all 128 raw bytes (a c_char array converts only up to a NUL)
+            dist.broadcast_object_list(box, src=0, group=group)
+            _uid_bytes = box[0]
+        ctypes.memmove(ctypes.byref(uid), _uid_bytes, 128)
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(self.dev):
             self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank))

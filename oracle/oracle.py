@@ -319,6 +319,19 @@ def set_epnp_refit_f64(on):
     lib().orc_set_epnp_refit_f64(ctypes.c_int(1 if on else 0))
 
 
+def set_epnp_moments(on):
+    """True (default) = the n-point EPnP systems (re-fit on the inliers, plain solvePnP) build M^T M and the absolute orientation from
+    moment sums, the kernel's form since round 5; False = entry by entry / two passes per candidate (round 4's form): the independent
+    check of that reformulation."""
+    lib().orc_set_epnp_moments(ctypes.c_int(1 if on else 0))
+
+
+def set_epnp_cv_early_return(on):
+    """Version-dependent decision (ii) of epnp.inc: True = OpenCV >= 3.3's early return for exactly five candidates (EPnP on the float32
+    inputs); False (default) = the float64 normalisation of every re-fit.  Four candidates: EPnP either way (P3P is not restated)."""
+    lib().orc_set_epnp_cv_early_return(ctypes.c_int(1 if on else 0))
+
+
 def set_lm_iter0_gradient_test(on):
     """Version-dependent decision (iii): True (default) = Ceres tests the gradient tolerance before the first step."""
     lib().orc_set_lm_iter0_gradient_test(ctypes.c_int(1 if on else 0))

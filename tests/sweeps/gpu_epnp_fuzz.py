@@ -7,6 +7,7 @@ import numpy as np, torch
 from monorun_amd import synthetic as syn
 from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_epnp_device
 from oracle import oracle as orc
+from tests import fuzz_cases
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(int(os.environ.get('SEED', 0)))
 def dv(a):
@@ -15,22 +16,9 @@ bad = 0
 nobj = 0
 nbad_valid = 0
 for trial in range(int(os.environ.get('TRIALS', 40))):
-    B = int(rng.choice([1, 3, 64, 200])); hw = int(rng.choice([3, 4, 8, 10, 28]))
-    b = syn.make_batch(B=B, hw=hw, seed=int(rng.integers(1 << 30)))
-    x2d, istd, x3d, K, ur, vr, thr = [np.array(a, copy=True) for a in syn.pnp_boundary(b, planar=bool(rng.integers(2)))]
-    P = x2d.shape[1]
     mode = trial % 10
-    sel = rng.uniform(size=B) < 0.5
-    if mode == 0: x3d[sel] = 0.0                                   # all points coincide
-    elif mode == 1: x2d[sel, rng.integers(P)] = np.nan             # NaN correspondences
-    elif mode == 2: istd[sel] = 0.0                                # zero weights
-    elif mode == 3: x3d[sel] *= 1e20                               # overflow
-    elif mode == 4: x3d[sel, :, 1] = 0.0                           # planar object (rank-2 covariance: one control point collapses)
-    elif mode == 5: x3d[sel] = rng.normal(0, 1, x3d[sel].shape).astype(np.float32)   # garbage geometry
-    elif mode == 6: thr[sel] = 0.0                                 # zero consensus threshold
-    elif mode == 7: x2d[sel] = np.inf
-    elif mode == 8: x3d[sel, :, 0] = 0.0; x3d[sel, :, 1] = 0.0     # collinear object
-    elif mode == 9: x3d[sel] = x3d[sel][:, :1]                     # every point the same 3-D point, different pixels
+    x2d, istd, x3d, K, ur, vr, thr = fuzz_cases.make_case(mode, rng)
+    B, P = x2d.shape[:2]
     with np.errstate(all='ignore'):
         ref = orc.u2d_pnp_epnp(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, return_init=True, num_threads=0)
     d = [dv(x2d), dv(istd), dv(x3d), dv(K), dv(ur), dv(vr), dv(thr)]

@@ -148,6 +148,47 @@ def test_kitti_harness_world_2_equals_one_rank(tmp_path):
         assert (tmp_path / 'split' / 'out_w1' / 'data' / f).read_text() == (tmp_path / 'split' / 'out_w2' / 'data' / f).read_text()
 
 
+def _agree_worker(rank, world, port, broken_rank, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if rank == broken_rank:
+        os.environ['MR_RCCL_LIBRARY'] = '/nonexistent/librccl.so'          # ONLY this rank cannot load the library
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from monorun_amd.parallel import agreed_rccl_all_gather
+    ag, why = agreed_rccl_all_gather(torch.device('cpu'))
+    # the job's next collective still lines up on every rank (nobody is stuck inside a broadcast the other never joined)
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)
+    q.put((rank, ag is None, why, int(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('broken_rank', [0, 1])
+def test_rccl_set_up_failure_on_one_rank_only_is_agreed(broken_rank):
+    """`agreed_rccl_all_gather` must deliver "every rank or none" when only SOME ranks fail.  World size 2 over gloo, one
+    rank with MR_RCCL_LIBRARY pointing nowhere: both ranks return (None, reason) — the healthy one because the job agreed, not because it
+    failed itself — and the job's following collective completes on both (before the fix the healthy rank sat in the id broadcast while the
+    broken one had already moved on to the all-reduce: mismatched collectives)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, broken_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1]
+    assert all(r[1] for r in res), 'a rank kept a private communicator the other rank does not have'
+    assert all(r[2] for r in res) and 'nonexistent' in res[broken_rank][2]
+    assert all(r[3] == 3 for r in res)
+
+
 def test_shard_bounds_cover_everything_once():
     from monorun_amd.parallel import shard_bounds, PackedResults, ROW_BYTES
     for n in (0, 1, 7, 8, 1024, 65536):

@@ -258,3 +258,66 @@ def test_version_dependent_decisions_are_switches(orc):
     finally:
         orc.set_lm_iter0_gradient_test(True)
     assert np.array_equal(base[2], g0[2]) and np.array_equal(base[1], g0[1])                   # no config-2 start is already stationary
+
+
+def test_moment_form_agrees_with_the_entry_wise_form(orc):
+    """since round 5 every n-point EPnP system (solvePnPRansac's re-fit on the inliers, plain solvePnP) builds M^T M from 40 moment
+    sums and the absolute orientation from 19 — in the oracle AND in the kernel, which it mirrors.  This keeps ONE independent check of the
+    reformulation: the entry-by-entry M^T M with two passes per candidate (round 4's form, orc.set_epnp_moments(False)) gives the same re-fit —
+    start poses within 1e-7, identical RANSAC masks (they are decided before the re-fit) — on ordinary config-2 objects (there also: post-LM
+    poses within the 1e-4 bar) and on adversarial classes of the fuzz set (planar / collinear object points, garbage geometry, zero thresholds)."""
+    from tests import fuzz_cases as fz
+    rng = np.random.default_rng(11)
+    cases = []
+    b = syn.make_batch(B=48, seed=77)
+    cases.append([np.ascontiguousarray(a) for a in syn.pnp_boundary(b, planar=False)])
+    for kind in ('planar', 'collinear', 'garbage', 'zero_threshold'):
+        cases.append([np.ascontiguousarray(a) for a in fz.make_case(kind, rng, B=16, hw=10, planar_layout=False)])
+    worst_init, worst_pose = 0.0, 0.0
+    for ci, (x2d, istd, x3d, Km, ur, vr, thr) in enumerate(cases):
+        run = lambda: orc.u2d_pnp_epnp(x2d, istd, x3d, Km, ur, vr, 0.5, 0.6, thr, True, return_init=True)
+        mom = run()
+        orc.set_epnp_moments(False)
+        try:
+            ent = run()
+        finally:
+            orc.set_epnp_moments(True)
+        assert np.array_equal(mom[5], ent[5]), 'RANSAC masks are decided before the re-fit: the form of its sums cannot move them'
+        both = mom[0] & ent[0] & np.isfinite(mom[6]).all(1) & np.isfinite(ent[6]).all(1)
+        # well-conditioned re-fits only: a planar / collinear set has a rank-deficient M^T M whose null-space basis any rounding turns
+        well = both & (np.abs(mom[6] - ent[6]).max(1) < 1e-3)
+        assert well.sum() >= 0.5 * max(1, both.sum()) or both.sum() == 0
+        if well.any():
+            worst_init = max(worst_init, float(np.abs(mom[6] - ent[6])[well].max()))
+            if ci == 0:                                   # post-LM poses: ordinary objects (a degenerate object's LM amplifies any rounding of its start)
+                assert well.all()
+                dy = np.abs(np.angle(np.exp(1j * (mom[1] - ent[1]))))
+                worst_pose = max(worst_pose, float(dy.max()), float(np.abs(mom[2] - ent[2]).max()))
+    assert 0.0 < worst_init < 1e-7, worst_init          # different sums (so not bit-equal), the same matrix to rounding
+    assert worst_pose <= 1e-4, worst_pose
+
+
+def test_opencv_early_return_switch_for_five_candidates(orc):
+    """Decision (ii) behind a switch: with exactly five candidates OpenCV >= 3.3 returns solvePnP(EPNP) on the float32
+    inputs; orc.set_epnp_cv_early_return(True) restates that (float32 normalisation), the default keeps the float64 normalisation of every
+    re-fit.  The two differ at the 1e-7 level in the start pose, never in the mask; four candidates are EPnP either way."""
+    rng = np.random.default_rng(5)
+    K = np.array([[707.0912, 0, 601.8873], [0, 707.0912, 183.1104], [0, 0, 1]], np.float32)
+    for n in (5, 4):
+        obj = (rng.random((n, 3)) * np.array([3.9, 1.5, 1.6]) - np.array([1.95, 1.5, 0.8])).astype(np.float32)
+        yaw, t = 0.4, np.array([1.0, 1.5, 14.0])
+        R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        pc = obj.astype(np.float64) @ R.T + t
+        img = np.stack([K[0, 0] * pc[:, 0] / pc[:, 2] + K[0, 2], K[1, 1] * pc[:, 1] / pc[:, 2] + K[1, 2]], 1).astype(np.float32)
+        r0 = orc.epnp_ransac(obj, img, K, 3.0)
+        orc.set_epnp_cv_early_return(True)
+        try:
+            r1 = orc.epnp_ransac(obj, img, K, 3.0)
+        finally:
+            orc.set_epnp_cv_early_return(False)
+        assert r0['ok'] and r1['ok'] and r0['mask'].all() and r1['mask'].all()
+        d = max(np.abs(r0['rvec'] - r1['rvec']).max(), np.abs(r0['tvec'] - r1['tvec']).max())
+        if n == 5:
+            assert 0.0 < d < 1e-4, d
+        else:
+            assert d == 0.0
