@@ -319,6 +319,35 @@ def set_epnp_refit_f64(on):
     lib().orc_set_epnp_refit_f64(ctypes.c_int(1 if on else 0))
 
 
+def set_cov_waves(waves):
+    """Summation tree of the covariance Hessian in u2d_pnp / u2d_pnp_epnp: the kernel's for `waves` waves per object (default 4 = what
+    the library launches for fewer than 2048 objects; 2 beyond; mr_pick_waves) — orc_cov_hessian_spec —, or 0 = sequential over the
+    points (rounds 1-5; orc_torch_jacobian)."""
+    lib().orc_set_cov_waves(ctypes.c_int(int(waves)))
+
+
+def cov_hessian_spec(K, z_min, u_range, v_range, yaw, t, x3d, istd, inlier, waves=4):
+    """The specified covariance Hessian of ONE object (orc_cov_hessian_spec): (4,4) float64."""
+    K, ur, vr, t = _d(K).reshape(9), _d(u_range).reshape(2), _d(v_range).reshape(2), _d(t).reshape(3)
+    x3d, istd = _d(x3d), _d(istd)
+    m = np.ascontiguousarray(np.asarray(inlier).astype(np.uint8)) if inlier is not None else None
+    H = np.zeros((4, 4))
+    lib().orc_cov_hessian_spec(_p(K, c_dp), ctypes.c_double(z_min), _p(ur, c_dp), _p(vr, c_dp), ctypes.c_double(float(yaw)), _p(t, c_dp), _p(x3d, c_dp), _p(istd, c_dp),
+                               _p(m, c_u8p) if m is not None else None, ctypes.c_int(x3d.shape[0]), ctypes.c_int(int(waves)), _p(H, c_dp))
+    return H
+
+
+def spec_sincos(x):
+    """The covariance stage's specified sin / cos (orc_spec_sincos: the twin of csrc/pnp_kernel.inc spec_sincos), element-wise."""
+    x = np.atleast_1d(_d(x))
+    sn, cs = np.zeros_like(x), np.zeros_like(x)
+    a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    for i, v in enumerate(x):
+        lib().orc_spec_sincos_export(ctypes.c_double(float(v)), ctypes.byref(a), ctypes.byref(b))
+        sn[i], cs[i] = a.value, b.value
+    return sn, cs
+
+
 def set_epnp_moments(on):
     """True (default) = the n-point EPnP systems (re-fit on the inliers, plain solvePnP) build M^T M and the absolute orientation from
     moment sums, the kernel's form since round 5; False = entry by entry / two passes per candidate (round 4's form): the independent

@@ -597,6 +597,119 @@ void orc_torch_jacobian(const double *K /*9*/, double z_min, const double *u_ran
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The covariance Hessian AS THE KERNEL'S STAGE 4 SPECIFIES IT (round 6; csrc/pnp_kernel_body.inc "stage 4", operation for operation):
+ * the same J^T J as orc_torch_jacobian up to rounding — the reference's own is a BLAS product of unspecified order (hessian.py:85-86), so
+ * neither is "the" order — but with every operation and the summation tree fixed, so that a Hessian that is singular to rounding
+ * (planar / collinear object points) factorises, or fails to, identically on both sides and `valid` can be compared bit for bit:
+ *   - sin / cos of the float32 yaw: orc_spec_sincos (Cody-Waite reduction + the minimax kernels, every fma written);
+ *   - no contraction anywhere else (oracle/Makefile: -ffp-contract=off), one IEEE division per point (iz = 1 / z), w = istd * iz;
+ *   - only the inliers contribute (outlier rows are ASSIGNED zero, jacobian.py:52-59); thread t of the object's 64 x waves threads
+ *     accumulates inliers t, t + 64 waves, ... in ascending order (q-th inlier = q-th set bit of the mask) with
+ *     acc = fma(Ju_i, Ju_j, fma(Jv_i, Jv_j, acc)); the 64 partials of a wave combine by the butterfly with strides 32, 16, 1, 2, 4, 8
+ *     (v_permlane32_swap, v_permlane16_swap, four DPP steps: epnp_tree64), the waves' totals add up in wave order.
+ * waves = the kernel's waves per object (4 for launches of fewer than 2048 objects, 2 beyond; mr_pick_waves), 1..8.
+ * ---------------------------------------------------------------------------------------- */
+static void orc_spec_sincos(double x, double *sn, double *cs) {
+    const double kd = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-kd, 1.57079632673412561417e+00, x);
+    r = fma(-kd, 6.07710050630396597660e-11, r);
+    r = fma(-kd, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double zr = z * r;
+    const double s = fma(zr, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double t1 = 1.0 - w, t2 = t1 - hz, zz = z * z;
+    const double c = w + fma(zz, pc, t2);
+    /* (int)kd as v_cvt_i32_f64 converts: saturating, NaN -> 0 */
+    const int qi = (kd != kd) ? 0 : (kd >= 2147483647.0 ? 2147483647 : (kd <= -2147483648.0 ? (-2147483647 - 1) : (int)kd));
+    const int q = qi & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+void orc_spec_sincos_export(double x, double *sn, double *cs) { orc_spec_sincos(x, sn, cs); }
+
+static double orc_tree64(double *p /* [64], destroyed */) {            /* = epnp_tree64 (epnp.inc is included further down) */
+    static const int stride[6] = { 32, 16, 1, 2, 4, 8 };
+    double q[64];
+    for (int t = 0; t < 6; ++t) { for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ stride[t]]; memcpy(p, q, sizeof q); }
+    return p[0];
+}
+
+void orc_cov_hessian_spec(const double *K /*9*/, double z_min, const double *u_range, const double *v_range,
+                          double yaw, const double *t, const double *pts3d, const double *istd, const uint8_t *inlier /*nullable: all*/,
+                          int pn, int waves, double *H /*16*/) {
+    double sn, cs;
+    orc_spec_sincos(yaw, &sn, &cs);
+    const double tx = t[0], ty = t[1], tz = t[2];
+    double kr[9], kt[3];
+    for (int r = 0; r < 3; ++r) {
+        kr[3 * r + 0] = K[3 * r + 0] * cs - K[3 * r + 2] * sn;
+        kr[3 * r + 1] = K[3 * r + 1];
+        kr[3 * r + 2] = K[3 * r + 0] * sn + K[3 * r + 2] * cs;
+        kt[r] = K[3 * r + 0] * tx + K[3 * r + 1] * ty + K[3 * r + 2] * tz;
+    }
+    const double m1[4] = { K[0] * (-sn) + K[2] * (-cs), K[0] * cs + K[2] * (-sn),
+                           K[3] * (-sn) + K[5] * (-cs), K[3] * cs + K[5] * (-sn) };
+    if (waves < 1) waves = 1;
+    if (waves > 8) waves = 8;
+    const int NT = 64 * waves;
+    double (*part)[10] = (double (*)[10])calloc((size_t)NT, sizeof(double[10]));
+    int qi = 0;
+    for (int i = 0; i < pn; ++i) {
+        if (inlier && !inlier[i]) continue;
+        double *hacc = part[qi % NT];
+        ++qi;
+        const double X = pts3d[3 * i], Y = pts3d[3 * i + 1], Z = pts3d[3 * i + 2];
+        const double un = kr[0] * X + kr[1] * Y + kr[2] * Z + kt[0];
+        const double vn = kr[3] * X + kr[4] * Y + kr[5] * Z + kt[1];
+        double z = kr[6] * X + kr[7] * Y + kr[8] * Z + kt[2];
+        const int zclip = z < z_min;
+        z = zclip ? z_min : z;
+        const double iz = 1.0 / z;
+        double uv[2] = { un * iz, vn * iz };
+        const int cl[2] = { (uv[0] < u_range[0]) || (uv[0] > u_range[1]), (uv[1] < v_range[0]) || (uv[1] > v_range[1]) };
+        uv[0] = fmax(u_range[0], fmin(u_range[1], uv[0]));
+        uv[1] = fmax(v_range[0], fmin(v_range[1], uv[1]));
+        double J[8];
+        for (int r = 0; r < 2; ++r) {
+            const int zero = zclip || cl[r];
+            const double w = istd[2 * i + r] * iz;
+            J[4 * r + 0] = zero ? 0.0 : w * ((m1[2 * r] + uv[r] * cs) * X + (m1[2 * r + 1] + uv[r] * sn) * Z);
+            J[4 * r + 1] = zero ? 0.0 : w * K[3 * r + 0];
+            J[4 * r + 2] = zero ? 0.0 : w * K[3 * r + 1];
+            J[4 * r + 3] = zero ? 0.0 : w * (K[3 * r + 2] - uv[r]);
+        }
+        int q = 0;
+        for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++q) hacc[q] = fma(J[a], J[b], fma(J[4 + a], J[4 + b], hacc[q]));
+    }
+    double tot[10];
+    for (int q = 0; q < 10; ++q) {
+        double acc = 0.0;
+        for (int w = 0; w < waves; ++w) {
+            double p64[64];
+            for (int l = 0; l < 64; ++l) p64[l] = part[64 * w + l][q];
+            const double ws = orc_tree64(p64);
+            acc = (w == 0) ? ws : acc + ws;
+        }
+        tot[q] = acc;
+    }
+    free(part);
+    int q = 0;
+    for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++q) H[4 * a + b] = H[4 * b + a] = tot[q];
+}
+
+/* ------------------------------------------------------------------------------------------
  * exact_hessian (hessian.py:5-64): h[i][j] = d/d pose_j of (J^T e)_i, which the reference obtains by torch autograd
  * through the ANALYTIC Jacobian expressions of get_pose_jacobians (jacobian.py:48-98) and the weighted error of
  * forward_proj (:4-45); the masks (z clip, per-axis uv clip, outliers) are constants for autograd and masked rows were
@@ -976,6 +1089,9 @@ static int orc_epnp_init(const float *x2d, const float *x3d, uint8_t *mask, int 
  * Inputs contiguous float32 (B,P,2),(B,P,2),(B,P,3); K (Kb,9), ranges (Rb,2) broadcast when Kb/Rb==1.
  * mask: in = istd inlier mask from the host (numpy) stage, out = final inlier mask.
  * ---------------------------------------------------------------------------------------- */
+static int orc_cov_waves = 4;   /* waves per object whose summation tree the covariance Hessian follows (orc_cov_hessian_spec); 0 = the sequential order of rounds 1-5 */
+void orc_set_cov_waves(int w) { orc_cov_waves = w < 0 ? 0 : (w > 8 ? 8 : w); }
+
 static void orc_one_object(const float *x2d, const float *istd, const float *x3d, const float *K,
                            const float *ur, const float *vr, const float *thr, const double *init,
                            int pn, double z_min, int inlier_opt_only, int n_hyp, int init_mode /* 0 = K0, 1 = EPnP/RANSAC restatement */,
@@ -1015,7 +1131,8 @@ static void orc_one_object(const float *x2d, const float *istd, const float *x3d
         for (int i = 0; i < 3 * pn; ++i) d3[i] = x3d[i];
         double Kd[9]; for (int i = 0; i < 9; ++i) Kd[i] = K[i];
         double urd[2] = { ur[0], ur[1] }, vrd[2] = { vr[0], vr[1] }, td[3] = { pose[1], pose[2], pose[3] }, H[16], C[16];
-        orc_torch_jacobian(Kd, z_min, urd, vrd, (double)pose[0], td, d2, d3, dw, mask, pn, NULL, NULL, H);
+        if (orc_cov_waves > 0) orc_cov_hessian_spec(Kd, z_min, urd, vrd, (double)pose[0], td, d3, dw, mask, pn, orc_cov_waves, H);      /* the kernel's specified order */
+        else orc_torch_jacobian(Kd, z_min, urd, vrd, (double)pose[0], td, d2, d3, dw, mask, pn, NULL, NULL, H);                            /* sequential (rounds 1-5) */
         if (!orc_pose_cov(H, C)) *valid = 0;
         for (int i = 0; i < 16; ++i) cov[i] = (float)C[i];
         free(d2);

@@ -545,3 +545,101 @@ def test_library_wave_rule_is_exported(dev):
         assert lib.mr_pick_waves(1024, 784) == 4 and lib.mr_pick_waves(4096, 784) == 2 and lib.mr_pick_waves(0, 784) < 0
     pipe = PnPPipeline(dev, depth=4, verify=False)
     assert pipe.flags_for(1024, 784) == 2 << _lib.MR_WAVES_SHIFT
+
+
+@pytest.mark.parametrize('flow,waves', [('epnp', 4), ('epnp', 2), ('epnp', 8), ('k0', 4), ('k0', 1), ('k0', 2)])
+def test_valid_flag_is_bit_exact_on_adversarial_objects(dev, orc, flow, waves):
+    """on planar / collinear / coincident / one-point objects the covariance Hessian J^T J (pnp_uncert.py:71-85,
+    hessian.py:84-86) is singular to rounding, and whether its Cholesky factorisation succeeds — the `valid` flag — used to depend on the order
+    of its sums (kernel: lane order; restatement: sequential; 2 of 135 227 objects in profiles/r05_epnp_fuzz_long.txt).  Since round 6 the
+    covariance stage is a SPECIFIED computation (csrc/pnp_kernel_body.inc stage 4 = oracle orc_cov_hessian_spec: no contraction, IEEE
+    division, the workgroup's own summation tree for its wave count): `valid` is compared bit for bit here, on every object, for the wave
+    counts the library launches (tests/sweeps/gpu_epnp_fuzz.py is the 2 000-trial version: profiles/r06_epnp_fuzz_long.txt)."""
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_device, pnp_uncert_epnp_device
+    from tests import fuzz_cases
+    rng = np.random.default_rng(100 + waves)
+    fl = waves << _lib.MR_WAVES_SHIFT
+    orc.set_cov_waves(waves)
+    n_obj = n_singular = n_other_pose = 0
+    try:
+        for trial in range(40):
+            mode = ('planar', 'collinear', 'coincident', 'one_point', 'garbage', 'planar', 'collinear', 'zero_threshold')[trial % 8]
+            x2d, istd, x3d, K, ur, vr, thr = fuzz_cases.make_case(mode, rng, hw=(28 if trial % 3 == 0 else None))
+            with np.errstate(all='ignore'):
+                ref = (orc.u2d_pnp_epnp if flow == 'epnp' else orc.u2d_pnp)(x2d, istd, x3d, K, ur, vr, 0.5, 0.6, thr, True, num_threads=0)
+            d = [_t(dev, a) for a in (x2d, istd, x3d, K, ur, vr, thr)]
+            if flow == 'epnp':
+                out = pnp_uncert_epnp_device(d[0], d[1], d[2], d[3], d[4], d[5], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=d[6], inlier_opt_only=True, flags=fl)
+            else:
+                out = pnp_uncert_device(d[0], d[1], d[2], d[3], d[4], d[5], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=d[6], inlier_opt_only=True, flags=fl)
+            torch.cuda.synchronize()
+            valid, pose, cov, mask = out[0].cpu().numpy().astype(bool), out[1].cpu().numpy(), out[2].cpu().numpy(), out[4].cpu().numpy().astype(bool)
+            assert np.array_equal(mask, ref[5]), (trial, mode, 'inlier mask')
+            rp = np.concatenate([ref[1], ref[2]], 1)
+            same = ((pose == rp) | (np.isnan(pose) & np.isnan(rp))).all(1)       # identical start + identical LM trajectory: the covariance stage sees the same float32 pose
+            n_other_pose += int((~same).sum())
+            assert np.array_equal(valid[same], ref[0][same]), (trial, mode, 'valid differs for objects', np.flatnonzero(same & (valid != ref[0]))[:8])
+            big = np.abs(cov).reshape(len(valid), -1).max(1) > 1e8
+            n_obj += len(valid); n_singular += int((big | ~valid).sum())
+    finally:
+        orc.set_cov_waves(4)
+    assert n_singular > 20, 'the cases are meant to contain objects whose Hessian is singular to rounding'
+    assert n_other_pose <= 0.01 * n_obj, (n_other_pose, n_obj)
+
+
+def test_config5_full_size_through_the_default_flow(dev, orc):
+    """BASELINE config 5 at its FULL size — 65 536 proposals x 56x56 correspondences, fp16 storage (2.9 GB of inputs) —
+    through the flow the boundary runs by default (the reference's initialiser + LM: `pnp_uncert_epnp_device`), in ONE call on one GPU
+    (tests/test_gpu_parity.py::test_config5_full_size_on_one_gpu is the same launch through the K0 fast mode): 256 distinct objects tiled
+    256x; the first tile against `orc.u2d_pnp_epnp` object by object (masks bit-exact, identical LM iteration counts, pose within 1e-4),
+    every other tile bit-equal to the first (results do not depend on batch position or on what else is in flight)."""
+    from monorun_amd.ops.least_squares.pnp_uncert import pnp_uncert_epnp_device
+    nd, rep, hw = 256, 256, 56
+    b = syn.make_batch(B=nd, hw=hw, seed=4321)
+    x2d, istd, x3d, K, ur, vr, thr = syn.pnp_boundary(b, planar=True)
+    mk = lambda a: np.ascontiguousarray(a.astype(np.float16).transpose(0, 2, 1))                     # (nd, C, P) fp16, channel-planar
+    t = lambda a: torch.from_numpy(a).to(dev)
+    big = [t(mk(a)).repeat(rep, 1, 1).permute(0, 2, 1) for a in (x2d, istd, x3d)]                    # (65536, P, C) views, strides (C*P, 1, P)
+    assert big[0].shape == (nd * rep, hw * hw, 2) and big[0].stride() == (2 * hw * hw, 1, hw * hw)
+    out = pnp_uncert_epnp_device(big[0], big[1], big[2], t(np.asarray(K)), t(np.asarray(ur)), t(np.asarray(vr)), z_min=0.5, epnp_istd_thres=0.6,
+                                 epnp_ransac_thres=t(np.asarray(thr)).repeat(rep), inlier_opt_only=True, with_diag=True)
+    torch.cuda.synchronize()
+    valid, pose, cov, tr, mask, diag = out[:6]
+    f32 = lambda a: np.ascontiguousarray(mk(a).astype(np.float32).transpose(0, 2, 1))              # the oracle sees the rounded values
+    ref = orc.u2d_pnp_epnp(f32(x2d), f32(istd), f32(x3d), K, ur, vr, 0.5, 0.6, thr, True, return_diag=True, num_threads=0)
+    r_ret, r_yaw, r_t, r_cov, r_tr, r_mask, r_diag = ref
+    v0, p0, c0, m0, d0 = [a[:nd].cpu().numpy() for a in (valid, pose, cov, mask, diag)]
+    assert np.array_equal(m0.astype(bool), r_mask) and np.array_equal(v0.astype(bool), r_ret)
+    assert np.array_equal(d0[:, 0], r_diag[:, 0]) and np.array_equal(d0[:, 2] % 16, r_diag[:, 2]), 'LM iteration counts / exit reasons'
+    ok = r_ret
+    dyaw = np.abs(np.angle(np.exp(1j * (p0[:, 0] - r_yaw[:, 0]))))
+    assert dyaw[ok].max() <= POSE_TOL and np.abs(p0[:, 1:] - r_t)[ok].max() <= POSE_TOL
+    scale = np.abs(r_cov[ok]).reshape(ok.sum(), -1).max(1)[:, None, None]
+    assert (np.abs(c0[ok] - r_cov[ok]) / scale).max() <= 1e-5
+    for v in (valid, pose, cov, tr, mask):
+        tiles = v.view(rep, nd, *v.shape[1:])
+        assert bool((tiles == tiles[:1]).all()), 'a later tile differs from the first'
+    assert float(valid.float().mean()) > 0.97
+
+
+def test_a_dropped_launch_frees_its_buffers_by_refcount(dev):
+    """PnPEpnpLaunch(fused=True) used to hold the launch set of its one call, whose `members` held the launch — a reference
+    cycle, so the ~17 MB-per-1024-object workspace, the outputs and the masks waited for the cyclic garbage collector.  Now the launch set
+    keeps argument lists only: dropping the last reference frees the tensors at once."""
+    import gc
+    import weakref
+    from monorun_amd import PnPEpnpLaunch
+    b = syn.make_batch(B=64, seed=5)
+    d = [_t(dev, a) for a in syn.pnp_boundary(b, planar=True)]
+    gc.collect()
+    gc.disable()
+    try:
+        l = PnPEpnpLaunch(*d[:6], z_min=0.5, epnp_istd_thres=0.6, epnp_ransac_thres=d[6], inlier_opt_only=True)
+        l.run()
+        torch.cuda.synchronize()
+        refs = [weakref.ref(l), weakref.ref(l.work), weakref.ref(l.mask)]
+        del l
+        assert all(r() is None for r in refs), 'a reference cycle keeps the launch (and its device buffers) alive until the cyclic GC runs'
+    finally:
+        gc.enable()

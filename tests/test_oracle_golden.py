@@ -163,3 +163,21 @@ def test_istd_mask_numpy_orders(orc, P):
     thr = np.float32(0.6) * (seq / np.float32(P))
     assert np.array_equal(m_c, (a >= thr[:, None, :]).all(2))
     assert m_p.shape == m_c.shape and (m_p != m_c).mean() < 0.01
+
+
+def test_specified_covariance_hessian_equals_the_reference_hessian_to_rounding(orc, g12):
+    """Round 6: the covariance Hessian the kernel's stage 4 specifies (orc_cov_hessian_spec: fixed operations, the workgroup's summation
+    tree for its wave count) IS the J^T J of jacobian.py / hessian.py:84-86 — it equals the reference's own fp64 output (fixture G2, masked)
+    to rounding for every wave count, with clamped points and partial masks in the set; different wave counts are different trees."""
+    B = g12['x2d'].shape[0]
+    differ = False
+    for b in range(B):
+        Hs = [orc.cov_hessian_spec(g12['K'][b], float(g12['z_min']), g12['u_range'][b], g12['v_range'][b], g12['yaw'][b], g12['t'][b],
+                                   g12['x3d'][b], g12['istd'][b], g12['inlier'][b], waves=w) for w in (1, 2, 4, 8)]
+        for H in Hs:
+            assert np.array_equal(H, H.T)
+            assert _rel(H, g12['h_f64'][b]) <= 1e-12, b
+        differ = differ or any(not np.array_equal(Hs[0], H) for H in Hs[1:])
+    assert differ
+    sn, cs = orc.spec_sincos(np.linspace(-7.0, 7.0, 2001))
+    assert np.abs(sn - np.sin(np.linspace(-7.0, 7.0, 2001))).max() <= 2.3e-16 and np.abs(cs - np.cos(np.linspace(-7.0, 7.0, 2001))).max() <= 2.3e-16
