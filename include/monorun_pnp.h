@@ -76,6 +76,10 @@ extern "C" {
 #define MR_EPNP_REFIT_F32   0x40      /* mr_epnp_ransac_batched: normalise the image points of solvePnPRansac's final re-fit in float32 (round 3's
                                          reading of OpenCV) instead of float64 (the published solvePnPRansac converts the inliers to CV_64F first;
                                          the default since round 4) — oracle/epnp.inc "version-dependent decisions" (i) */
+#define MR_EPNP_CV_EARLY_RETURN 0x1000 /* mr_epnp_ransac_batched / _grouped: restate OpenCV >= 3.3's early return of solvePnPRansac for EXACTLY FIVE candidates
+                                         (`model_points == npoints`: solvePnP(EPNP) on the float32 inputs, no CV_64F conversion -> float32 normalisation
+                                         of the image points) instead of the float64 normalisation every re-fit uses (the default; oracle/epnp.inc
+                                         decision (ii), orc_set_epnp_cv_early_return).  Four candidates (P3P inside OpenCV) are EPnP either way. */
 #define MR_EPNP_DEFER_REFIT 0x80      /* mr_epnp_ransac_batched / _grouped: stop before the last launch (the re-fit's pose candidates on the inliers):
                                          init_mask is final, init_pose / init_valid / diag are NOT written — mr_pnp_uncert_from_epnp_grouped, given
                                          the same (caller-owned, required) workspace on the same stream, does that work as the prologue of the LM

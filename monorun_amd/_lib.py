@@ -20,6 +20,7 @@ MR_MEAN_AUTO, MR_MEAN_SEQUENTIAL, MR_MEAN_PAIRWISE = 0, 1, 2
 MR_NO_ISTD_MASK, MR_COV_NONE, MR_COV_CERES, MR_ANY_ORDER = 0x4, 0x8, 0x10, 0x20
 MR_EPNP_REFIT_F32 = 0x40
 MR_EPNP_DEFER_REFIT = 0x80
+MR_EPNP_CV_EARLY_RETURN = 0x1000
 MR_WAVES_SHIFT = 8
 MR_LM_MAXIT_SHIFT = 16
 MR_EPNP_FIRST_ROUND_SHIFT = 24

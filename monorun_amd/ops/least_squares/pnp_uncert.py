@@ -151,7 +151,7 @@ def pnp_uncert_epnp_device(coords_2d, coords_2d_istd, coords_3d, cam_mats, u_ran
     dev = coords_2d.device
     if dev.type != 'cuda':
         raise RuntimeError('monorun_amd EPnP/RANSAC runs on an MI355X only (no CPU fallback)')
-    iflags = int(flags) & 0x47                     # the bits the initialiser reads: istd mean order, MR_NO_ISTD_MASK, MR_EPNP_REFIT_F32
+    iflags = int(flags) & 0x1047                   # the bits the initialiser reads: istd mean order, MR_NO_ISTD_MASK, MR_EPNP_REFIT_F32, MR_EPNP_CV_EARLY_RETURN
     if first_round is not None:
         iflags |= max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT
     B, P = int(coords_2d.shape[0]), int(coords_2d.shape[1])
@@ -309,7 +309,7 @@ class PnPEpnpLaunch:
         self.diag = torch.empty(B, 4, **f32) if with_diag else None
         self.B = B
         head = [x2d.data_ptr(), _strides(x2d), istd.data_ptr(), _strides(istd), x3d.data_ptr(), _strides(x3d), _DTYPES[x2d.dtype], cam.data_ptr(), cam.shape[0]]
-        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), (int(flags) & 0x47) | ((max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT) if first_round is not None else 0),
+        self.args_init = head + [thr.data_ptr() if thr is not None else None, B, P, float(epnp_istd_thres), (int(flags) & 0x1047) | ((max(1, min(30, int(first_round))) << _lib.MR_EPNP_FIRST_ROUND_SHIFT) if first_round is not None else 0),
                                  int(max_iters), self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),
                                  self.init_diag.data_ptr() if self.init_diag is not None else None, None, self.work.data_ptr(), self.work.numel()]
         self.args_lm = head + [ur.data_ptr(), vr.data_ptr(), ur.shape[0], self.init_pose.data_ptr(), self.init_mask.data_ptr(), self.init_valid.data_ptr(),

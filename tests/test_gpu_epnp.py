@@ -643,3 +643,37 @@ def test_a_dropped_launch_frees_its_buffers_by_refcount(dev):
         assert all(r() is None for r in refs), 'a reference cycle keeps the launch (and its device buffers) alive until the cyclic GC runs'
     finally:
         gc.enable()
+
+
+def test_opencv_early_return_switch_mirrors_the_restatement(dev, orc):
+    """oracle/epnp.inc decision (ii) behind a switch on both sides: with EXACTLY five istd candidates OpenCV >= 3.3 returns
+    solvePnP(EPNP) on the float32 inputs; MR_EPNP_CV_EARLY_RETURN / orc.set_epnp_cv_early_return(True) restate that (float32 normalisation of the
+    image points), the default keeps the float64 normalisation of every re-fit.  The kernel follows the restatement either way (start pose to
+    INIT_TOL, all five points inliers), the two settings differ from each other (the switch is live), and objects with more candidates do not
+    notice it."""
+    from monorun_amd import _lib
+    from monorun_amd.ops.least_squares.pnp_uncert import epnp_ransac_device
+    b = syn.make_batch(B=24, hw=8, seed=31)
+    x2d, istd, x3d, K, ur, vr, thr = [np.array(a, copy=True) for a in syn.pnp_boundary(b, planar=False)]
+    rng = np.random.default_rng(2)
+    five = np.arange(24) % 2 == 0
+    for i in np.flatnonzero(five):                        # exactly five points pass the istd test (0.6 x the mean of each axis)
+        keep = rng.choice(x2d.shape[1], 5, replace=False)
+        istd[i] = 0.001
+        istd[i, keep] = 1.0
+    d = [_t(dev, a) for a in (x2d, istd, x3d, K, thr)]
+    got = {}
+    for early in (False, True):
+        orc.set_epnp_cv_early_return(early)
+        try:
+            refs = _stage_reference(orc, x2d, istd, x3d, K, thr)
+        finally:
+            orc.set_epnp_cv_early_return(False)
+        assert all(r['n'] == 5 for r, f in zip(refs, five) if f)
+        gpu = epnp_ransac_device(d[0], d[1], d[2], d[3], epnp_istd_thres=0.6, epnp_ransac_thres=d[4], with_diag=True, debug_hypotheses=True,
+                                 flags=_lib.MR_EPNP_CV_EARLY_RETURN if early else 0)
+        torch.cuda.synchronize()
+        _check_stage(gpu, refs)
+        got[early] = gpu[0].cpu().numpy()
+    dd = np.abs(got[True] - got[False])
+    assert 0.0 < dd[five].max() < 1e-2 and dd[~five].max() == 0.0, (dd[five].max(), dd[~five].max())
