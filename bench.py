@@ -9,7 +9,7 @@ started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gp
 
 A "step" is one pass of the hot path over one synthetic batch that is already resident in HBM: ONE CALL of the op as the
 reference's config dict builds it — the reference's flow: istd mask -> cv2.solvePnPRansac(EPNP, 30 iterations) restated
-(six launches + its re-fit's pose candidates as the prologue of the next) -> LM -> covariance (one launch), through the C ABI — over 1024 objects per GPU, plus — when N > 1 — the
+(five launches one call at a time, six per launch set, + its re-fit's pose candidates as the prologue of the next) -> LM -> covariance (one launch), through the C ABI — over 1024 objects per GPU, plus — when N > 1 — the
 single RCCL all-gather of the packed per-object results (north_star: "objects shard across the GPUs with an RCCL all-gather
 of poses").  `--flow k0` measures the explicit one-launch fast mode instead (rounds 1-4's `value`); the default line carries
 it under `k0_fast_mode`.  Weak scaling: every rank owns 1024 objects per step.  The steps
@@ -45,6 +45,7 @@ P = HW * HW
 SEED = 1234
 # in = P*(2+2+3)*4 + 36 + 16 + 4 ; out = 16 + 64 + 4 + 1 + P  ->  22 877 B / solve (fp32, P = 784)
 BYTES_PER_SOLVE = P * 7 * 4 + 36 + 16 + 4 + 16 + 64 + 4 + 1 + P
+LAUNCHES_TEXT = '6 launches per call of fewer than 2048 objects (front, hypotheses, consensus, the second round as ONE launch, re-fit betas, re-fit + LM + covariance), 7 per launch set (the second round as its two compact launches)'
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
 FLOP_PER_POINT_EVAL = 80        # projection ~20, Jacobian ~24, 12 FMA J^T J, 6 FMA J^T r, cost
@@ -624,7 +625,7 @@ def run(args):
         torch.cuda.synchronize()
         ini_ms = np.array([a.elapsed_time(b) for a, b, c in ev3[NB:]]); lm_ms = np.array([b.elapsed_time(c) for a, b, c in ev3[NB:]])
         split = {'initialiser_launches_ms': float(ini_ms.mean()), 'lm_launch_ms': float(lm_ms.mean()), 'lm_launch_ms_per_batch': [float(v) for v in lm_ms],
-                 'what': 'one call at a time, HIP events on the launch stream around the six launches of mr_epnp_ransac_grouped (MR_EPNP_DEFER_REFIT) and around the LM launch that carries the re-fit (mr_pnp_uncert_from_epnp_grouped), averaged over the batches'}
+                 'what': 'one call at a time, HIP events on the launch stream around the launches of mr_epnp_ransac_grouped (MR_EPNP_DEFER_REFIT: front, hypotheses, consensus, second round, re-fit betas — five for a call of fewer than 2048 objects, six for a launch set) and around the LM launch that carries the re-fit (mr_pnp_uncert_from_epnp_grouped), averaged over the batches'}
 
     if rank == 0:
         total = B_PER_GPU * world * args.steps
@@ -701,12 +702,12 @@ def run(args):
                        'flow': ("reference: the drop-in boundary's default — PnPUncert built from the reference's config dict (configs/kitti_car.py:118-126)" if ref_flow else
                                 "k0: the explicit fast mode, PnPUncert(initialiser='k0')"),
                        'stages': ('istd mask + cv2.solvePnPRansac(EPNP, 30 iterations) restated (front / hypotheses / consensus / re-fit launches) + LM (Ceres-1.14 semantics, fp64) '
-                                  '+ covariance: 7 launches per call or launch set (the last one = the re-fit\'s pose candidates, then LM + covariance)' if ref_flow else
+                                  '+ covariance: ' + LAUNCHES_TEXT + ' (the last one = the re-fit\'s pose candidates, then LM + covariance)' if ref_flow else
                                   'istd mask + K0 consensus initialiser (32 hyp.) + LM (Ceres-1.14 semantics, fp64) + covariance: one fused launch'),
                        'calls_per_launch_set': LG,
                        'launches_in_flight': L, 'launches_in_flight_asked': L_ASKED, 'stream_overlap_test': pipe_of(L_ASKED).overlap_test, 'waves_per_object': {'in_flight': (fl_main >> 8) & 15 or 'library heuristic (4)', 'isolated_launch': (fl_one >> 8) & 15 or 'library heuristic (4)'},
                        'issue': ((f'steps issued on {L} HIP streams by monorun_amd.PnPPipeline, {LG} consecutive steps per launch set (monorun_amd.PnPEpnpGroupLaunch: the '
-                                  "every launch of the set — the initialiser's six and the re-fit / LM / covariance launch — carries the objects of the set's calls, every call keeps its own input tensors and result buffers); "
+                                  "every launch of the set — the initialiser's six and the re-fit / LM / covariance launch: seven — carries the objects of the set's calls, every call keeps its own input tensors and result buffers); "
                                   if LG > 1 else f'steps issued round-robin on {L} HIP streams by monorun_amd.PnPPipeline (one completion event per result buffer); ') +
                                  f'every step is one full {B_PER_GPU}-object call into its own buffers, all outputs complete inside the timed window '
                                  'and verified bit-identical to isolated calls after it') if L > 1 else 'one stream: every launch waits for the previous one',
@@ -715,14 +716,14 @@ def run(args):
             'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          # filled in below: `achieved` / `frac` describe the TIMED REGIME (the kernel instantiation and issue pattern `value` was measured on)
                          'achieved': None, 'frac': None,
-                         'kernel': (f'reference flow, 7 launches per call or launch set (epnp_front / epnp_hyp / epnp_consensus x 2 rounds, epnp_refit_betas, pnp_uncert_refit_kernel<{"__half" if stress else "float"}, {((fl_main >> 8) & 15) or 4}>); longest: the last one (re-fit prologue + LM + covariance)' if ref_flow else
+                         'kernel': (f'reference flow, ' + LAUNCHES_TEXT + f' (epnp_front / epnp_hyp / epnp_consensus / second round: epnp_round2 or epnp_hyp + epnp_consensus / epnp_refit_betas / pnp_uncert_refit_kernel<{"__half" if stress else "float"}, {((fl_main >> 8) & 15) or 4}>); longest: the last one (re-fit prologue + LM + covariance)' if ref_flow else
                                     (f'pnp_uncert_kernel<float, {((fl_main >> 8) & 15) or 4}, false>' if not stress else f'pnp_uncert_kernel<__half, {((fl_main >> 8) & 15) or "auto"}, false>')),
                          'launches_in_flight': L,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': BYTES_PER_SOLVE * B_PER_GPU,
                          'isolated_launch': {
                              'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'kernel': ('one whole call of the reference flow (its 8 launches back to back on one stream)' if ref_flow else
+                             'kernel': ('one whole call of the reference flow (its 6 launches back to back on one stream)' if ref_flow else
                                         (f'pnp_uncert_kernel<float, {((fl_one >> 8) & 15) or 4}, false>' if not stress else 'pnp_uncert_kernel<__half, auto, false>')),
                              'kernel_ms_avg': kernel_ms, 'kernel_ms_min': float(k_ms.min()),
                              'kernel_ms_median': float(np.median(k_ms)), 'kernel_ms_p95': float(np.percentile(k_ms, 95)), 'kernel_ms_per_batch': per_batch_ms,
@@ -737,8 +738,8 @@ def run(args):
                                    'model': f'{FLOP_PER_POINT_EVAL} FLOP x inlier points x (LM iterations + 2) per object (SURVEY 8d; iterations and inlier '
                                             'counts read back from the kernel in this run); K0 and the mask are not counted; rate per ISOLATED launch',
                                    'lm_iteration_histogram': {str(k): it_hist[k] for k in sorted(it_hist)}},
-                         'note': ('formally HBM-bound (each launch streams the tile once); in practice VALU issue bound: ~49 M fp64-heavy wave-instructions per call '
-                                  '(profiles/r05_epnp_valu_per_launch.txt), the stages are latency chains (DESIGN.md section 3)' if ref_flow else
+                         'note': ('formally HBM-bound (three of the launches stream the object\'s rows once each); in practice the stages are serial fp64 latency chains per object one call at a time, '
+                                  'and issue slots x workgroup residency with launch sets in flight (wave-instruction counts per launch: `isolated_launch.valu_issue`, DESIGN.md section 3)' if ref_flow else
                                   'formally HBM-bound (read-once streaming); in practice VALU/latency-bound: the tile is LDS-resident across all LM iterations (DESIGN.md)')},
             'value_cold': prewarm.get('window_before', {}).get('value'),      # the same window in a just-started process (before the reported pre-conditioning): compare THIS with rounds 1-3
             'valid_fraction': valid_frac,
@@ -752,7 +753,7 @@ def run(args):
         line['rotation_normalised'] = dict(rn, what=f'the same loop timed over {rn["steps"]} steps = a whole number of rotations over the {NB} batches '
                                                     '(--steps need not be a multiple of --batches, and the batches take different times)')
         if 'single_stream' in variants:
-            line['single_stream'] = dict(per_s(variants['single_stream']), what=('ONE CALL AT A TIME: the same steps on one stream, every call (its 8 launches) waits for the previous one'
+            line['single_stream'] = dict(per_s(variants['single_stream']), what=('ONE CALL AT A TIME: the same steps on one stream, every call (its 6 launches) waits for the previous one'
                                          if ref_flow else 'the same steps on ONE stream (launches_in_flight = 1): every launch '
                                          'waits for the previous one and so pays its slowest object; what rounds 1-2 reported as `value`'))
         if 'grouped_collective' in variants:

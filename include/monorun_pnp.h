@@ -155,9 +155,10 @@ int mr_pnp_uncert_batched(
  * diag (B,4) f32 or NULL [RANSAC iterations run, inliers of the best model, candidates, index of the best model],
  * debug_hypotheses (B,30,12) f64 or NULL (every hypothesis' R | t; tests).  Feed the three outputs to
  * mr_pnp_uncert_from_init_batched for the LM + covariance.
- * The call is a sequence of seven launches on `stream` (sample set-up; speculative hypotheses in two rounds — MR_EPNP_FIRST_ROUND — one
- * launch per round that takes a sample to its three candidate poses, consensus + OpenCV's sequential loop replayed over the counts; the
- * re-fit's eigenvectors + beta candidates; the re-fit) that hand their intermediate results over in
+ * The call is a sequence of six or seven launches on `stream` (sample set-up; speculative hypotheses in two rounds — MR_EPNP_FIRST_ROUND —: a
+ * launch that takes a sample to its three candidate poses and one for consensus + OpenCV's sequential loop replayed over the counts; the second
+ * round is ONE launch for fewer than 2048 objects — a workgroup per object that leaves at once unless its loop wants more — and the same two
+ * compact launches beyond; the re-fit's eigenvectors + beta candidates; the re-fit) that hand their intermediate results over in
  * `workspace`: device memory of at least mr_epnp_workspace_bytes(B, P) bytes, 256-byte aligned, owned by the caller and free to be
  * reused once the work queued on `stream` has passed it (17 MB per 1024 objects).  workspace = NULL: the library takes it from a
  * stream-ordered memory pool OF ITS OWN (one per device, created on first use, freed blocks kept for the next call: hipMallocFromPoolAsync /

@@ -34,7 +34,7 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_kernel_body.inc"), os.path.join(_HERE, "csrc", "pnp6_kernel.inc"), os.path.join(_HERE, "csrc", "hessian_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_eig_low4.inc"), os.path.join(_HERE, "csrc", "epnp_stages.inc"), os.path.join(_HERE, "csrc", "kitti_eval_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
+    deps = [SRC, os.path.join(_HERE, "csrc", "pnp_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_kernel_body.inc"), os.path.join(_HERE, "csrc", "pnp6_kernel.inc"), os.path.join(_HERE, "csrc", "hessian_kernel.inc"), os.path.join(_HERE, "csrc", "pnp_noc_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_kernel.inc"), os.path.join(_HERE, "csrc", "epnp_eig_low4.inc"), os.path.join(_HERE, "csrc", "epnp_stages.inc"), os.path.join(_HERE, "csrc", "epnp_consensus_body.inc"), os.path.join(_HERE, "csrc", "kitti_eval_kernel.inc"), os.path.join(INCLUDE, "monorun_pnp.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

@@ -1019,7 +1019,7 @@ int grant_lds(const void *fn, size_t lds) {
     return MR_OK;
 }
 
-// The staged form of the initialiser (epnp_stages.inc): twelve launches on `st` (four of them idle when no object needs a second round), intermediate results in `workspace` (caller's, at
+// The staged form of the initialiser (epnp_stages.inc): six or seven launches on `st` (the second round idles when no object needs it: one launch for small sets, two beyond), intermediate results in `workspace` (caller's, at
 // least mr_epnp_workspace_bytes(B, P)) or, when that is null, in a stream-ordered allocation of the device's default memory pool.
 template <typename T>
 int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_bytes, int first_round, hipStream_t st) {
@@ -1083,10 +1083,19 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
         // replayed loop still wants iterations after `first` (ptsetreg.cpp's adaptive bound: with few outliers it drops to a
         // handful after the first good model — config-2 batches: 1.5 iterations on average, 8 at most).  Same results either way.
         const int first = first_round < 1 ? 1 : (first_round > kEpMaxIters ? kEpMaxIters : first_round);
+        // small launch sets (one call at a time): the second round as ONE launch (epnp_round2_kernel); launch sets in flight keep the two compact ones
+        static const int r2_env = [] { const char *e = getenv("MR_EP_ROUND2"); return e ? atoi(e) : 0; }();      // development: 1 = always two launches, 2 = always one
+        const bool one_launch_round2 = cons_wpo == 4 && (kEpMaxIters - first) <= kEpRound2Quads && first < kEpMaxIters && (r2_env == 2 || (r2_env == 0 && a.B < 2048));
         for (int round = 0; round < 2; ++round) {
             ea.h0 = round == 0 ? 0 : first; ea.h1 = round == 0 ? first : kEpMaxIters;
             const int nh = ea.h1 - ea.h0;
             if (nh <= 0) break;
+            if (round == 1 && one_launch_round2) {
+                const size_t lds_2 = epnp_round2_lds_bytes(a) + MR_EP_LDS_PAD_CONS;
+                if ((r = grant_lds((const void *)epnp_round2_kernel<T>, lds_2)) != MR_OK) return r;
+                hipLaunchKernelGGL((epnp_round2_kernel<T>), dim3(a.B), dim3(256), lds_2, st, ea);
+                break;
+            }
             const long long quads = (long long)a.B * nh;
             // 16 quads per single-wave workgroup: 8 / 4 per wave (more waves, fewer matrices in lockstep) measured 74 / 140 us against 74 us one call
             // at a time and 5.4 / 4.1 against 6.3 M solves/s in flight (profiles/r04_epnp_quads_per_wave.txt)
