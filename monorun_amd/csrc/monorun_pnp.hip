@@ -1084,6 +1084,10 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
         // handful after the first good model — config-2 batches: 1.5 iterations on average, 8 at most).  Same results either way.
         const int first = first_round < 1 ? 1 : (first_round > kEpMaxIters ? kEpMaxIters : first_round);
         // small launch sets (one call at a time): the second round as ONE launch (epnp_round2_kernel); launch sets in flight keep the two compact ones
+        // development / tests: force the quads per matrix (0, 2 or 4 levels) of both lane-mapped launches (MR_EP_WIDE) or of one (MR_EP_WIDE_HYP, MR_EP_WIDE_BETAS)
+        static const auto lv_env = [](const char *name) { const char *e = getenv(name); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 4) ? v : -1; };
+        static const int wide_env = lv_env("MR_EP_WIDE");
+        static const int wide_hyp_env = lv_env("MR_EP_WIDE_HYP") >= 0 ? lv_env("MR_EP_WIDE_HYP") : wide_env, wide_betas_env = lv_env("MR_EP_WIDE_BETAS") >= 0 ? lv_env("MR_EP_WIDE_BETAS") : wide_env;
         static const int r2_env = [] { const char *e = getenv("MR_EP_ROUND2"); return e ? atoi(e) : 0; }();      // development: 1 = always two launches, 2 = always one
         const bool one_launch_round2 = cons_wpo == 4 && (kEpMaxIters - first) <= kEpRound2Quads && first < kEpMaxIters && (r2_env == 2 || (r2_env == 0 && a.B < 2048));
         for (int round = 0; round < 2; ++round) {
@@ -1099,11 +1103,23 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             const long long quads = (long long)a.B * nh;
             // 16 quads per single-wave workgroup: 8 / 4 per wave (more waves, fewer matrices in lockstep) measured 74 / 140 us against 74 us one call
             // at a time and 5.4 / 4.1 against 6.3 M solves/s in flight (profiles/r04_epnp_quads_per_wave.txt)
-            hipLaunchKernelGGL(epnp_hyp_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(64), 0, st, ea);
+            // wide form (a wave per hypothesis) while that still leaves SIMDs without a wave: up to 1024 hypotheses (one image's <= 100 proposals x the first
+            // round of 10).  Measured, one call at a time (profiles/r06_wide_sweep.txt): B = 100: -6 us; a 16-lane row per hypothesis at B = 200 / 320: +-0; a wave
+            // at B = 200: +40 us (2000 waves: the chip is full and its clock drops)
+            const int lv_h = wide_hyp_env >= 0 ? wide_hyp_env : (quads <= 1024 ? 4 : 0);
+            if (lv_h == 4) hipLaunchKernelGGL(epnp_hyp_kernel<4>, dim3((unsigned)quads), dim3(64), 0, st, ea);
+            else if (lv_h == 2) hipLaunchKernelGGL(epnp_hyp_kernel<2>, dim3((unsigned)((quads + 3) / 4)), dim3(64), 0, st, ea);
+            else hipLaunchKernelGGL(epnp_hyp_kernel<0>, dim3((unsigned)((quads + 15) / 16)), dim3(64), 0, st, ea);
             if (cons_wpo == 2) hipLaunchKernelGGL((epnp_consensus_kernel<T, 2>), dim3(a.B), dim3(128), lds_c, st, ea);
             else hipLaunchKernelGGL((epnp_consensus_kernel<T, 4>), dim3(a.B), dim3(256), lds_c, st, ea);
         }
-        hipLaunchKernelGGL(epnp_refit_betas_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);      // (8 / 4 / 2 quads per wave: 67 / 68 / 102 us against 55 us)
+        {   // (quad form with 8 / 4 / 2 quads per wave: 67 / 68 / 102 us against 55 us, round 4)
+            // a wave per object up to 512 objects, a 16-lane row up to 2047 (B = 100: -10 us, 512: -5, 1024: -5 with rows, +16 with waves), the quad form for launch sets
+            const int lv_b = wide_betas_env >= 0 ? wide_betas_env : (a.B <= 512 ? 4 : (a.B < 2048 ? 2 : 0));
+            if (lv_b == 4) hipLaunchKernelGGL(epnp_refit_betas_kernel<4>, dim3((unsigned)a.B), dim3(64), 0, st, ea);
+            else if (lv_b == 2) hipLaunchKernelGGL(epnp_refit_betas_kernel<2>, dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, ea);
+            else hipLaunchKernelGGL(epnp_refit_betas_kernel<0>, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, ea);
+        }
         if (!(a.flags & MR_EPNP_DEFER_REFIT))                  // else: the LM launch carries it (mr_pnp_uncert_from_epnp_grouped)
             hipLaunchKernelGGL((epnp_refit_kernel<T>), dim3(a.B), dim3(kEpPoseThreads), lds_r, st, ea);
         HIP_TRY(hipGetLastError());

@@ -678,3 +678,22 @@ def test_opencv_early_return_switch_mirrors_the_restatement(dev, orc):
     dd = np.abs(got[True] - got[False])
     # (five noisy points determine a pose badly: the two normalisations can land far apart — what matters is that the kernel lands where the restatement does)
     assert dd[five].max() > 0.0 and dd[~five].max() == 0.0, (dd[five].max(), dd[~five].max())
+
+
+def test_wide_launches_equal_the_quad_launches(dev):
+    """Round 6: launches that would leave most SIMDs without a wave map a hypothesis / a re-fit to a 16-lane row or to a whole wave instead of a quad
+    (csrc/epnp_stages.inc epnp_hyp_kernel<LV>, epnp_refit_betas_kernel<LV>): the extra quads take LV levels of the eigen-solver's bisection per round.
+    Same midpoints, same comparisons: EVERY output of the flow — valid, pose, covariance, radius, masks, start poses, diagnostics — is bit-identical
+    for the three mappings (the library reads MR_EP_WIDE once per process, so each mapping runs in its own; sha256 over all outputs of all batches)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for lv in ('0', '2', '4'):
+        env = dict(os.environ, MR_EP_WIDE=lv, OBJECTS='37,300', NBATCH='3')
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_wide_ab.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600).stdout.decode()
+        rows = [l for l in out.splitlines() if 'sha256 of all outputs' in l]
+        assert len(rows) == 2, out[-2000:]
+        digests[lv] = [r.split('sha256 of all outputs')[1].strip() for r in rows]
+    assert digests['0'] == digests['2'] == digests['4'], digests
