@@ -616,7 +616,7 @@ def test_bench_line_describes_the_regime_it_measured():
     assert d['metric'].startswith('PnP solves/sec') and d['unit'] == 'solves/s' and d['dtype'] == 'f64' and d['n_gpus'] == 1 and d['steps'] == 8
     assert d['config']['flow'].startswith('reference') and 1 <= d['config']['calls_per_launch_set'] <= 8 and 'solvePnPRansac' in d['config']['stages']
     rf = d['roofline']
-    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and rf['kernel'].startswith('reference flow, 7 launches') and rf['launches_in_flight'] >= 1
+    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and rf['kernel'].startswith('reference flow, 6 launches per call of fewer than 2048 objects') and '7 per launch set' in rf['kernel'] and rf['launches_in_flight'] >= 1
     chip = d['value'] * rf['algorithmic_bytes_per_launch'] / 1024 / 1e9                   # algorithmic bytes of all calls / wall time
     assert abs(rf['achieved'] - chip) <= 1e-6 * chip and abs(rf['frac'] - chip / 8000.0) <= 1e-9
     dk = rf['dominant_kernel']
@@ -630,6 +630,11 @@ def test_bench_line_describes_the_regime_it_measured():
     sp = ref['launch_split']
     assert sp['initialiser_launches_ms'] > sp['lm_launch_ms'] > 0 and abs(sp['initialiser_launches_ms'] + sp['lm_launch_ms'] - iso['kernel_ms_avg']) < 0.2 * iso['kernel_ms_avg']
     assert d['outputs_verified'] is True and d['valid_fraction'] > 0.95
+    pi = ref['per_image_B100']                                 # the regime the pipeline runs (one image, 100 proposals) through the DEFAULT flow
+    assert pi['objects'] == 100 and pi['valid'] >= 95 and pi['outputs_of_the_three_paths_equal'] is True and pi['gpu_us_per_call_hip_events'] > 0
+    for row in ('eager_pose_from_head', 'prepared_launch', 'hip_graph_replay'):
+        assert pi[row]['wall_us_per_call_synced'] > 0 and pi[row]['issue_us_per_call'] > 0
+    assert '6 launches' in iso['kernel'] and (iso['valu_issue'] is None or iso['valu_issue']['valu_insts_per_call'] > 1e6)
     pw = d['config']['prewarm']                                # the untimed pre-conditioning is reported, with the window as a cold process sees it
     assert pw['launches'] > 0 and pw['launches_asked'] > 0 and pw['ms'] > 0 and pw['window_before']['steps'] == 8 and pw['window_before']['value'] > 0
     k0 = d['k0_fast_mode']                                     # the child run's line, condensed
