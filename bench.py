@@ -1235,11 +1235,17 @@ def per_image_latency(torch, syn, dev, batch0, args, n_obj=100, calls=300, refer
         out[name] = {'wall_us_per_call_synced': wall * 1e6, 'wall_us_per_call_event_polled': spin * 1e6, 'issue_us_per_call': issue * 1e6,
                      'us_per_call_back_to_back': thru * 1e6}
     ref = call()
-    for k in ('yaw_pred', 't_vec_pred', 'pose_cov_calib', 'inlier_mask'):      # the three paths are the same kernel on the same data
-        assert torch.equal(ref[k], prepared.out[k]) and torch.equal(ref[k], graph.out[k]), k
+    for k in ('yaw_pred', 't_vec_pred', 'pose_cov_calib', 'inlier_mask'):      # the three paths are the same kernels on the same data
+        assert torch.equal(prepared.out[k], graph.out[k]), k
+        if reference_flow and k == 'pose_cov_calib':
+            # the module path calibrates with three torch operations (uncert_prop_pnp_optimizer.py:96-97, monorun_roi_head.py:530-534), the prepared launches in the
+            # LM launch's epilogue: the same float32 formula, exp from two libraries — equal to rounding
+            assert torch.allclose(ref[k], prepared.out[k], rtol=2e-6, atol=0.0), k
+        else:
+            assert torch.equal(ref[k], prepared.out[k]), k
     out['objects'] = n_obj
     out['valid'] = int(ref['ret_val'].sum().item())
-    out['outputs_of_the_three_paths_equal'] = True
+    out['outputs_of_the_three_paths_equal'] = True          # (the eager module path's calibrated covariance to 2e-6 relative in the reference flow: see above)
     # GPU time of one call: HIP events on the launch stream around prepared launches issued one at a time
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
     for e0, e1 in evs:
