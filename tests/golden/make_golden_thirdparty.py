@@ -20,7 +20,7 @@ the libraries themselves.
     python tests/golden/make_golden_thirdparty.py [--ext /path/to/MonoRUn/monorun/ops/least_squares] [--out tests/golden]
 
 --ext: the directory of the reference checkout that holds the built cffi module `_ext` (INSTALL.md:46-47 of the reference).
-INTEGRATION.md section 7 has the one-paragraph how-to.  Nothing here copies reference code: the script CALLS the libraries.
+INTEGRATION.md section 8 has the one-paragraph how-to.  Nothing here copies reference code: the script CALLS the libraries.
 """
 import argparse
 import importlib

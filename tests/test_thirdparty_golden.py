@@ -22,7 +22,7 @@ import pytest
 from oracle import oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-HOWTO = 'python tests/golden/make_golden_thirdparty.py  (INTEGRATION.md section 7)'
+HOWTO = 'python tests/golden/make_golden_thirdparty.py  (INTEGRATION.md section 8)'
 
 
 def _load(name, needs):
