@@ -1106,7 +1106,7 @@ int launch_epnp_stages(EpnpStageArgs &ea, void *workspace, size_t workspace_byte
             // wide form (a wave per hypothesis) while that still leaves SIMDs without a wave: up to 1024 hypotheses (one image's <= 100 proposals x the first
             // round of 10).  Measured, one call at a time (profiles/r06_wide_sweep.txt): B = 100: -6 us; a 16-lane row per hypothesis at B = 200 / 320: +-0; a wave
             // at B = 200: +40 us (2000 waves: the chip is full and its clock drops)
-            const int lv_h = wide_hyp_env >= 0 ? wide_hyp_env : (quads <= 1024 ? 4 : 0);
+            const int lv_h = wide_hyp_env >= 0 ? wide_hyp_env : (quads <= 1024 ? 4 : (quads <= 4096 ? 2 : 0));      // (rows up to 4096 hypotheses: B = 128 ... 400: -9 ... -3 us; 5120: +30)
             if (lv_h == 4) hipLaunchKernelGGL(epnp_hyp_kernel<4>, dim3((unsigned)quads), dim3(64), 0, st, ea);
             else if (lv_h == 2) hipLaunchKernelGGL(epnp_hyp_kernel<2>, dim3((unsigned)((quads + 3) / 4)), dim3(64), 0, st, ea);
             else hipLaunchKernelGGL(epnp_hyp_kernel<0>, dim3((unsigned)((quads + 15) / 16)), dim3(64), 0, st, ea);
