@@ -163,9 +163,13 @@ int mr_pnp_uncert_batched(
  * reused once the work queued on `stream` has passed it (17 MB per 1024 objects).  workspace = NULL: the library takes it from a
  * stream-ordered memory pool OF ITS OWN (one per device, created on first use, freed blocks kept for the next call: hipMallocFromPoolAsync /
  * hipFreeAsync on `stream`); the process's default pool and its attributes are not touched.  Pass a workspace for steady-state use.
+ * Result-neutral tuning knobs, read once per process, for measurements and tests only: MR_EPNP_FIRST_ROUND=n; MR_EP_ROUND2=1 | 2 = the second round always as two
+ * launches | always as one; MR_EP_WIDE / MR_EP_WIDE_HYP / MR_EP_WIDE_BETAS = 0 | 2 | 4 = a quad | a 16-lane row | a wave per hypothesis / per re-fit instead of the
+ * library's rule by launch size (small launches get rows or waves: the extra quads shorten the matrix's latency chain).  Every setting gives bit-identical outputs
+ * (tests/test_gpu_epnp.py::test_wide_launches_equal_the_quad_launches).
  * VERSION-DEPENDENT DECISIONS (oracle/epnp.inc): with thresholds, an object with exactly FOUR (only possible when P = 4) or FIVE candidates
  * deliberately differs from OpenCV >= 3.3 as published, whose solvePnPRansac returns early when model_points == npoints (P3P's pose for
- * four points, float32 EPnP for five): here both get EPnP on the candidates with the float64 normalisation of every re-fit, all of them
+ * four points, float32 EPnP for five): here both get EPnP on the candidates with the float64 normalisation of every re-fit (MR_EPNP_CV_EARLY_RETURN restates the five-candidate early return), all of them
  * inliers; P3P and its solvability test are not restated.  P >= 6 candidates (every shipped configuration) is unaffected.
  * MR_EPNP_REFIT_F32 selects round 3's float32 re-fit.
  */
