@@ -160,7 +160,7 @@ int mr_pnp_uncert_batched(
  * round is ONE launch for fewer than 2048 objects — a workgroup per object that leaves at once unless its loop wants more — and the same two
  * compact launches beyond; the re-fit's eigenvectors + beta candidates; the re-fit) that hand their intermediate results over in
  * `workspace`: device memory of at least mr_epnp_workspace_bytes(B, P) bytes, 256-byte aligned, owned by the caller and free to be
- * reused once the work queued on `stream` has passed it (17 MB per 1024 objects).  workspace = NULL: the library takes it from a
+ * reused once the work queued on `stream` has passed it (11.5 MB per 1024 objects of 784 correspondences).  workspace = NULL: the library takes it from a
  * stream-ordered memory pool OF ITS OWN (one per device, created on first use, freed blocks kept for the next call: hipMallocFromPoolAsync /
  * hipFreeAsync on `stream`); the process's default pool and its attributes are not touched.  Pass a workspace for steady-state use.
  * Result-neutral tuning knobs, read once per process, for measurements and tests only: MR_EPNP_FIRST_ROUND=n; MR_EP_ROUND2=1 | 2 = the second round always as two

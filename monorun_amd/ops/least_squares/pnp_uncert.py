@@ -259,7 +259,7 @@ class PnPEpnpLaunch:
     """A prepared launch of the REFERENCE's flow over device-resident inputs: its initialiser (``mr_epnp_ransac_batched``: the
     launches of csrc/epnp_stages.inc, pnp_uncert_cpu.py:33-68) followed by the LM + covariance launch
     (``mr_pnp_uncert_from_init_batched``) on the same stream.  Outputs, the initialiser's hand-over buffers and its workspace
-    (``mr_epnp_workspace_bytes``: 17 MB per 1024 objects) are allocated once; ``run()`` only enqueues.  The stages are latency
+    (``mr_epnp_workspace_bytes``: 11.5 MB per 1024 objects) are allocated once; ``run()`` only enqueues.  The stages are latency
     chains that leave most issue slots of the chip idle, so several of these launches in flight (``PnPPipeline.submit``)
     overlap almost for free."""
 
@@ -324,7 +324,7 @@ class PnPEpnpLaunch:
         self.fused = bool(fused)
         if self.fused:
             # the launch set of this one call.  It keeps argument lists (raw pointers into tensors THIS object owns), not this object: no
-            # reference cycle, so the workspace / outputs / masks (~17 MB per 1024 objects) are freed by refcount when the launch is dropped
+            # reference cycle, so the workspace / outputs / masks (~11.5 MB per 1024 objects) are freed by refcount when the launch is dropped
             # — a serving loop that builds launches per request does not wait for the cyclic GC
             self._single = PnPEpnpGroupLaunch([self], work=self.work, lm='fused')
             self._single.members = ()
